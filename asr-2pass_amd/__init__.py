@@ -1,0 +1,270 @@
+"""asr-2pass_amd — MI355X-native Paraformer acoustic-model forward behind the FunASR `Model` seam.
+
+The product is the gfx950 shared library `libpfhip.so` (C ABI in include/pfhip.h, sources in csrc/).
+This Python module is only the ctypes binding used by the tests and bench.py, plus `ParaformerHip`,
+a thin mirror of the reference's plug-in interface (`funasr::Model`, onnxruntime/include/model.h:13-46;
+batched contract onnxruntime/src/paraformer-torch.cpp:301-475) with the same method names and error
+behaviour.  There is NO CPU fallback: if the HIP library is missing or a HIP call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpfhip.so")
+
+PFHIP_NUM_KCLASS = 8
+KCLASS_NAMES = ["gemm", "attention", "layernorm", "fsmn", "fbank", "cif", "head", "other"]
+
+# every symbol include/pfhip.h declares (tests check the built library exports exactly these)
+ABI_SYMBOLS = [
+    "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_destroy",
+    "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
+    "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
+    "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
+]
+
+
+class PfhipError(RuntimeError):
+    pass
+
+
+class _Out(ctypes.Structure):
+    _fields_ = [
+        ("token_ids", ctypes.POINTER(ctypes.c_int32)),
+        ("token_num", ctypes.POINTER(ctypes.c_int32)),
+        ("n_fires", ctypes.POINTER(ctypes.c_int32)),
+        ("n_frames", ctypes.POINTER(ctypes.c_int32)),
+        ("logp", ctypes.POINTER(ctypes.c_float)),
+        ("max_tokens", ctypes.c_int32),
+    ]
+
+
+class _Profile(ctypes.Structure):
+    _fields_ = [
+        ("ms", ctypes.c_double * PFHIP_NUM_KCLASS),
+        ("launches", ctypes.c_int64 * PFHIP_NUM_KCLASS),
+        ("flops", ctypes.c_double * PFHIP_NUM_KCLASS),
+        ("bytes", ctypes.c_double * PFHIP_NUM_KCLASS),
+    ]
+
+
+_lib = None
+
+
+def load_lib() -> ctypes.CDLL:
+    """Loads libpfhip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PfhipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.pfhip_last_error.restype = ctypes.c_char_p
+    lib.pfhip_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    lib.pfhip_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    lib.pfhip_destroy.argtypes = [vp]
+    lib.pfhip_destroy.restype = None
+    for f in ("pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model"):
+        getattr(lib, f).argtypes = [vp]
+    lib.pfhip_offline_forward.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ci, ctypes.POINTER(_Out)]
+    lib.pfhip_offline_enqueue.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ci), ci, vp]
+    lib.pfhip_offline_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
+    lib.pfhip_extract_feats.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ctypes.c_size_t, vp]
+    lib.pfhip_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.pfhip_profile_enable.argtypes = [vp, ci]
+    lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
+    _lib = lib
+    return lib
+
+
+def _check(lib, st):
+    if st != 0:
+        raise PfhipError(f"pfhip status {st}: {lib.pfhip_last_error().decode()}")
+
+
+class ParaformerHip:
+    """Host-side mirror of `funasr::Model` for the offline Paraformer path.
+
+    InitAsr   <-> Paraformer::InitAsr          (onnxruntime/src/paraformer.cpp:21-53)
+    Forward   <-> Model::Forward(float** din, int* len, bool input_finished, hw_emb, decoder, batch_in)
+                  (model.h:31-32; paraformer.cpp:463-589; paraformer-torch.cpp:301-475)
+    GetAsrSampleRate / SetBatchSize / GetBatchSize as in model.h:40-42.
+    Token ids -> text (Vocab::Vector2StringV2, vocab.cpp:164) is host string handling outside the
+    hot path: Forward joins vocabulary entries when a token list is given, else
+    returns space-separated ids.
+    """
+
+    def __init__(self):
+        self._lib = load_lib()
+        self._h = ctypes.c_void_p()
+        self._batch_size = 1
+        self._vocab: Optional[List[str]] = None
+        self.cfg = None
+
+    # -- lifetime ----------------------------------------------------------------------------------
+    def InitAsr(self, am_model, am_cmvn=None, am_config=None, token_file=None, thread_num=1, device=0):
+        """am_model: path prefix of `<prefix>.bin/.json`, or a (manifest dict, float32 blob) pair.
+        am_cmvn/am_config are folded into the container (cmvn.* tensors, config block)."""
+        if self._h:
+            self._lib.pfhip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        if isinstance(am_model, (tuple, list)):
+            man, blob = am_model
+            blob = np.ascontiguousarray(blob, dtype=np.float32)
+            _check(self._lib, self._lib.pfhip_create_from_memory(
+                blob.ctypes.data, blob.nbytes, json.dumps(man).encode(), device, ctypes.byref(self._h)))
+            self.cfg = man["config"]
+        else:
+            _check(self._lib, self._lib.pfhip_create(
+                (am_model + ".bin").encode(), (am_model + ".json").encode(), device, ctypes.byref(self._h)))
+            with open(am_model + ".json") as f:
+                self.cfg = json.load(f)["config"]
+        if token_file:
+            with open(token_file) as f:
+                self._vocab = json.load(f)
+        return self
+
+    def close(self):
+        if self._h:
+            self._lib.pfhip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def GetAsrSampleRate(self):
+        return self._lib.pfhip_sample_rate(self._h)
+
+    def SetBatchSize(self, n):
+        self._batch_size = int(n)
+
+    def GetBatchSize(self):
+        return self._batch_size
+
+    def StartUtterance(self):  # paraformer.cpp:297-307: stateless
+        pass
+
+    def EndUtterance(self):
+        pass
+
+    def Reset(self):
+        pass
+
+    @property
+    def vocab_size(self):
+        return self._lib.pfhip_vocab_size(self._h)
+
+    # -- the hot path --------------------------------------------------------------------------------
+    def forward_ids(self, din: Sequence[np.ndarray], want_logp=False, max_tokens=None):
+        """Batched forward.  Returns dict(token_num, n_fires, n_frames, ids=list of int arrays,
+        logp=list of [n_fires, V] arrays or None)."""
+        B = len(din)
+        if B == 0:
+            raise PfhipError("empty batch")
+        bufs = [np.ascontiguousarray(x, dtype=np.float32) for x in din]
+        lens = (ctypes.c_int * B)(*[int(b.shape[0]) for b in bufs])
+        ptrs = (ctypes.c_void_p * B)(*[b.ctypes.data if b.shape[0] else None for b in bufs])
+        if max_tokens is None:
+            max_tokens = max(1, max(int(b.shape[0]) for b in bufs) // 960 + 2)   # <= T+1 fires per utterance
+        V = self.vocab_size
+        ids = np.zeros((B, max_tokens), np.int32)
+        tn = np.zeros(B, np.int32)
+        nf = np.zeros(B, np.int32)
+        fr = np.zeros(B, np.int32)
+        logp = np.zeros((B, max_tokens, V), np.float32) if want_logp else None
+        out = _Out()
+        out.token_ids = ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.token_num = tn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.n_fires = nf.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.n_frames = fr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.logp = logp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_logp else None
+        out.max_tokens = max_tokens
+        _check(self._lib, self._lib.pfhip_offline_forward(self._h, ptrs, lens, B, None, 0, ctypes.byref(out)))
+        return dict(token_num=tn, n_fires=nf, n_frames=fr,
+                    ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)],
+                    logp=[logp[b, :nf[b]].copy() for b in range(B)] if want_logp else None)
+
+    def Forward(self, din, len_=None, input_finished=True, hw_emb=None, decoder_handle=None, batch_in=1):
+        """Same contract as Model::Forward: returns batch_in strings; an utterance that yields no
+        feature frame gives "" (paraformer.cpp:477-480)."""
+        din = list(din)[:batch_in]
+        if len_ is not None:
+            din = [np.asarray(x)[:n] for x, n in zip(din, len_)]
+        r = self.forward_ids(din)
+        res = []
+        for ids in r["ids"]:
+            if self._vocab is not None:
+                res.append("".join(self._vocab[i] for i in ids))
+            else:
+                res.append(" ".join(str(int(i)) for i in ids))
+        return res
+
+    def extract_feats(self, din: Sequence[np.ndarray]):
+        """FbankKaldi + LfrCmvn (paraformer.cpp:309-323, 421-461) on the GPU; list of [T_b, 560]."""
+        B = len(din)
+        bufs = [np.ascontiguousarray(x, dtype=np.float32) for x in din]
+        lens = (ctypes.c_int * B)(*[int(b.shape[0]) for b in bufs])
+        ptrs = (ctypes.c_void_p * B)(*[b.ctypes.data if b.shape[0] else None for b in bufs])
+        fd = self._lib.pfhip_feat_dim(self._h)
+        cap = sum(max(0, (int(b.shape[0]) - 400) // 160 + 1 + 5) // 6 + 1 for b in bufs) * fd
+        feats = np.zeros(cap, np.float32)
+        nfr = np.zeros(B, np.int32)
+        _check(self._lib, self._lib.pfhip_extract_feats(self._h, ptrs, lens, B, feats.ctypes.data, cap, nfr.ctypes.data))
+        out, o = [], 0
+        for b in range(B):
+            out.append(feats[o * fd:(o + int(nfr[b])) * fd].reshape(int(nfr[b]), fd).copy())
+            o += int(nfr[b])
+        return out
+
+    def get_tensor(self, name: str, cap_floats: int) -> np.ndarray:
+        buf = np.zeros(cap_floats, np.float32)
+        n = ctypes.c_size_t(0)
+        _check(self._lib, self._lib.pfhip_get_tensor(self._h, name.encode(), buf.ctypes.data, cap_floats, ctypes.byref(n)))
+        return buf[:n.value]
+
+    # -- device-resident form (bench.py) -------------------------------------------------------------
+    def enqueue_device(self, d_pcm_ptr: int, sample_off: np.ndarray, n_samples: np.ndarray, stream: int = 0):
+        B = len(n_samples)
+        so = np.ascontiguousarray(sample_off, np.int64)
+        ns = np.ascontiguousarray(n_samples, np.int32)
+        _check(self._lib, self._lib.pfhip_offline_enqueue(
+            self._h, ctypes.c_void_p(d_pcm_ptr), so.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            ns.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), B, ctypes.c_void_p(stream) if stream else None))
+
+    def fetch(self, B: int, max_tokens: int):
+        ids = np.zeros((B, max_tokens), np.int32)
+        tn = np.zeros(B, np.int32)
+        nf = np.zeros(B, np.int32)
+        fr = np.zeros(B, np.int32)
+        out = _Out()
+        out.token_ids = ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.token_num = tn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.n_fires = nf.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.n_frames = fr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.logp = None
+        out.max_tokens = max_tokens
+        _check(self._lib, self._lib.pfhip_offline_fetch(self._h, ctypes.byref(out)))
+        return dict(token_num=tn, n_fires=nf, n_frames=fr, ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)])
+
+    def profile_enable(self, on=True):
+        _check(self._lib, self._lib.pfhip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        p = _Profile()
+        _check(self._lib, self._lib.pfhip_profile_read(self._h, ctypes.byref(p), 1 if reset else 0))
+        return {KCLASS_NAMES[i]: dict(ms=p.ms[i], launches=p.launches[i], flops=p.flops[i], bytes=p.bytes[i])
+                for i in range(PFHIP_NUM_KCLASS)}

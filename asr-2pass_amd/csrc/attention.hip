@@ -1,0 +1,199 @@
+// Fused multi-head attention (SAN-M self-attention and decoder cross-attention), d_k = 128, fp32 on
+// v_mfma_f32_32x32x2_f32, flash-style online softmax.  Stands in for the MatMul/Softmax/MatMul nodes
+// of every attention block inside the reference's `m_session_->Run` (onnxruntime/src/paraformer.cpp:541).
+//
+// One workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 query rows and
+// keeps its Q slice in registers.  Key/value tiles of 32 keys are staged global -> registers -> LDS,
+// double buffered.  Per tile a wave computes S^T = K * Q^T (key on the MFMA row, query on the lane:
+// "swapped QK^T"), so that
+//   * a query's 32 scores live in one lane pair (l, l^32): row max / row sum = 16 register ops + one
+//     cross-half shuffle, no LDS;
+//   * P^T is already laid out as the B operand of O^T += V^T * P^T — the probabilities never leave
+//     their registers; V^T fragments are read from the row-major V tile with conflict-free
+//     ds_read_b32 (32 consecutive d per lane half);
+//   * O^T keeps the query on the lane too, so the online-softmax rescale is a per-lane scalar multiply.
+// The output tile is transposed through LDS once at the end and stored as full 512-B rows.
+// Keys >= kv_len are masked to -inf; tile rows past the segment end are clamped to the last valid
+// row, so no out-of-segment memory is read.
+#include "kernels.h"
+
+#include <math.h>
+
+namespace pfhip {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kQW = 32;            // query rows per wave
+constexpr int kQB = 128;           // query rows per block
+constexpr int kKT = 32;            // keys per tile
+constexpr int kKS = kHeadDim + 4;  // padded K-tile row stride (floats): conflict-free ds_read_b128
+constexpr int kKVBuf = kKT * kKS + kKT * kHeadDim;  // floats per (K,V) buffer
+constexpr int kLdsFloats = (2 * kKVBuf > 4 * kQW * kKS) ? 2 * kKVBuf : 4 * kQW * kKS;
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(
+    const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+    const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
+    const int* __restrict__ q_off, const int* __restrict__ q_len, const int* __restrict__ kv_off,
+    const int* __restrict__ kv_len, float scale) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int Lq = q_len[b];
+  const int q0 = blockIdx.x * kQB;
+  if (q0 >= Lq) return;
+  const int Lk = kv_len[b];
+  const size_t qbase = (size_t)q_off[b], kbase = (size_t)kv_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- Q slice of this lane: row q0 + wave*32 + r, d = 8*kb + 4*h + kk -------------------------
+  float4 qreg[16];
+  {
+    int qrow = q0 + wave * kQW + r;
+    if (qrow >= Lq) qrow = Lq - 1;
+    const float* qp = Q + (qbase + qrow) * ldq + head * kHeadDim + 4 * h;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) qreg[kb] = *reinterpret_cast<const float4*>(qp + kb * 8);
+  }
+
+  // ---- K/V tile staging --------------------------------------------------------------------------
+  const int lrow = tid >> 5, lc4 = tid & 31;   // 8 rows x 32 float4 per pass, 4 passes
+  float4 rk[4], rv[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = kt * kKT + lrow + 8 * i;
+      if (key >= Lk) key = Lk - 1;
+      rk[i] = *reinterpret_cast<const float4*>(K + (kbase + key) * ldk + head * kHeadDim + 4 * lc4);
+      rv[i] = *reinterpret_cast<const float4*>(V + (kbase + key) * ldv + head * kHeadDim + 4 * lc4);
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* ks = lds + buf * kKVBuf;
+    float* vs = ks + kKT * kKS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(ks + (lrow + 8 * i) * kKS + 4 * lc4) = rk[i];
+      *reinterpret_cast<float4*>(vs + (lrow + 8 * i) * kHeadDim + 4 * lc4) = rv[i];
+    }
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nkt = (Lk + kKT - 1) / kKT;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) gload(kt + 1);
+    const float* ks = lds + cur * kKVBuf;
+    const float* vs = ks + kKT * kKS;
+
+    // S^T[key][q] = sum_d K[key][d] * Q[q][d]
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    const float* kp = ks + r * kKS + 4 * h;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+      const float4 a = *reinterpret_cast<const float4*>(kp + kb * 8);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[kb].x, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[kb].y, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[kb].z, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[kb].w, sacc, 0, 0, 0);
+    }
+
+    // online softmax for query column r; this lane holds keys (e&3) + 8*(e>>2) + 4*h of the tile
+    float tmax = -INFINITY;
+    const int key0 = kt * kKT + 4 * h;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = key0 + (e & 3) + 8 * (e >> 2);
+      const float sv = (key < Lk) ? sacc[e] * scale : -INFINITY;
+      sacc[e] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = expf(sacc[e] - m_new);
+      sacc[e] = pv;
+      psum += pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    }
+
+    // O^T[d][q] += sum_key V[key][d] * P^T[key][q]
+    const float* vp = vs + (4 * h) * kHeadDim + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float* vrow = vp + ((e & 3) + 8 * (e >> 2)) * kHeadDim;
+      const float pb = sacc[e];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], pb, oacc[dt], 0, 0, 0);
+    }
+
+    if (kt + 1 < nkt) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise, transpose through LDS, store full rows ------------------------------------------
+  const float inv_l = 1.0f / l_run;
+  float* os = lds + wave * (kQW * kKS);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 o4;
+      o4.x = oacc[dt][4 * g + 0] * inv_l;
+      o4.y = oacc[dt][4 * g + 1] * inv_l;
+      o4.z = oacc[dt][4 * g + 2] * inv_l;
+      o4.w = oacc[dt][4 * g + 3] * inv_l;
+      // registers 4g..4g+3 are d = dt*32 + 8g + 4h + (0..3) of query column r
+      *reinterpret_cast<float4*>(os + r * kKS + dt * 32 + 8 * g + 4 * h) = o4;
+    }
+  }
+  __syncthreads();
+  // each wave stores its own 32 x 128 tile: 2 rows per pass (32 lanes x float4 = one 512-B row)
+#pragma unroll
+  for (int pass = 0; pass < 16; ++pass) {
+    const int row = pass * 2 + h;
+    const int qrow = q0 + wave * kQW + row;
+    if (qrow < Lq) {
+      const float4 o4 = *reinterpret_cast<const float4*>(os + row * kKS + 4 * r);
+      *reinterpret_cast<float4*>(O + (qbase + qrow) * ldo + head * kHeadDim + 4 * r) = o4;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                      float* O, int ldo, const int* q_off, const int* q_len, const int* kv_off,
+                      const int* kv_len, int B, int H, int max_q_len, float scale, hipStream_t s) {
+  if (B <= 0 || max_q_len <= 0) return;
+  const dim3 grid((max_q_len + kQB - 1) / kQB, H, B), block(256);
+  hipLaunchKernelGGL(attention_kernel, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off,
+                     q_len, kv_off, kv_len, scale);
+}
+
+}  // namespace pfhip

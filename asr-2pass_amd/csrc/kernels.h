@@ -1,0 +1,80 @@
+// Internal launcher declarations for the gfx950 kernels behind include/pfhip.h.
+// All pointers are device pointers unless a name says host.  All launches are asynchronous on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pfhip {
+
+constexpr int kTileM = 128;      // GEMM block tile rows   (activation buffers are allocated in multiples)
+constexpr int kTileN = 128;      // GEMM block tile cols   (weights are repacked/padded to multiples)
+constexpr int kTileK = 32;       // GEMM k-step            (K is padded to multiples)
+constexpr int kHeadDim = 128;    // attention kernel is specialised for d_k = 128
+constexpr int kMelW = 32;        // max taps per mel triangle (80 bins @ 512-pt FFT need <= 19)
+
+// ---- front end (SURVEY §8a rows a2,a3) -------------------------------------------------------
+struct FbankTables {
+  const float* window;     // [400] hamming, feature-window.cc:33-42
+  const double* tw512;     // [256][2] cos/-sin of 2*pi*k/512
+  const int* mel_off;      // [n_mels]
+  const int* mel_size;     // [n_mels]
+  const float* mel_w;      // [n_mels][kMelW]
+  const float* cmvn_mean;  // [lfr_m*n_mels]
+  const float* cmvn_istd;  // [lfr_m*n_mels]
+};
+// pcm: utterances back to back; sample_off[b] (int64), frame_off[b] prefix of fbank frame counts
+// (B+1 entries), nframes[b], row_off[b] (first LFR row of utterance b in feats).
+void launch_fbank_lfr_cmvn(const float* pcm, const int64_t* sample_off, const int* frame_off,
+                           const int* nframes, const int* row_off, int B, int total_frames,
+                           FbankTables tb, float* feats, hipStream_t s);
+
+// x0[row][0..D) = feats*scale + PE(row_pos[row]+1); columns D..ldx are zeroed.
+void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_pos, int M,
+                  const float* inv_timescale, float scale, hipStream_t s);
+
+// ---- dense ops --------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) (+R1[M,N]) (+R2[M,N]) (ReLU)   — fp32 MFMA 32x32x2.
+// A rows must be allocated up to a multiple of 128, K % 32 == 0, W has ceil(N/128)*128 rows of K.
+void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+                     const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+                     int M, int N, int K, bool relu, hipStream_t s);
+
+// y[row][0..D) = LN(x[row][0..D)) * g + b; columns D..Dout zeroed.  D % 4 == 0, Dout <= 2048.
+void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
+                      int M, int D, int Dout, float eps, hipStream_t s);
+
+// out[t][c] = (res? res[t][c] : 0) + v[t][c] + sum_j w[c][j] * v[t + j - (k-1)/2][c], per utterance
+// segment [off[b], off[b]+len[b]) with zero padding outside the segment.  C % 4 == 0, k == 11.
+void launch_fsmn(const float* v, int ldv, const float* w, const float* res, int ldres, float* out,
+                 int ldo, const int* off, const int* len, int B, int max_len, int C, hipStream_t s);
+
+// Multi-head attention, d_k = 128: O[q, h*128:(h+1)*128] = softmax(scale * Q_h K_h^T) V_h over the
+// utterance's own keys.  q segments (q_off,q_len), kv segments (kv_off,kv_len), all device arrays.
+void launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                      float* O, int ldo, const int* q_off, const int* q_len, const int* kv_off,
+                      const int* kv_len, int B, int H, int max_q_len, float scale, hipStream_t s);
+
+// ---- predictor / CIF (SURVEY §8a rows a4,a12) -------------------------------------------------
+// col[row] = [h[t-1] | h[t] | h[t+1]] with zeros outside the utterance.  row_pos/row_len give the
+// local index and utterance length of every packed row.
+void launch_im2col3(const float* h, int ldh, float* col, int ldc, const int* row_pos,
+                    const int* row_len, int M, int D, hipStream_t s);
+// alphas[row] = relu(sigmoid(dot(o[row], w) + b) * smooth - noise)
+void launch_alpha(const float* o, int ldo, const float* w, const float* b, float smooth,
+                  float noise, float* alphas, int M, int D, hipStream_t s);
+// CIF integrate-and-fire per utterance (paraformer-online.cpp:301-327) with the tail slot
+// (alpha = tail, hidden = 0) appended.  Writes fired frames to stage[(row_off[b]+b+n)][0..D),
+// n_fires[b], token_num[b] = floor(sequential fp32 sum of alphas incl. tail).
+void launch_cif(const float* hidden, int ldh, const float* alphas, const int* row_off,
+                const int* len, int B, int D, float threshold, float tail, float* stage,
+                int* n_fires, int* token_num, hipStream_t s);
+// emb[tok_off[b]+n] = stage[row_off[b]+b+n]
+void launch_compact(const float* stage, float* emb, const int* tok_row_src, int ML, int D,
+                    hipStream_t s);
+
+// ---- head -----------------------------------------------------------------
+// per row: log-softmax over V logits, argmax (first max wins, util.cpp:63-74).  logp may be null.
+void launch_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids,
+                              hipStream_t s);
+
+}  // namespace pfhip

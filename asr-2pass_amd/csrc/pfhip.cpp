@@ -1,0 +1,806 @@
+// C-ABI implementation (include/pfhip.h): model container + launch sequence of the offline
+// Paraformer forward on one MI355X.  Layout in HBM:
+//   * all utterances of a batch are PACKED row-major with no padding rows: utterance b owns LFR rows
+//     [row_off[b], row_off[b]+T_b) of every [M, *] activation matrix (M = sum T_b); the reference's
+//     GPU flavour zero-pads to Tmax instead (onnxruntime/src/paraformer-torch.cpp:342-347);
+//   * decoder-side matrices are packed the same way over the CIF-fired tokens (ML = sum fires);
+//   * weights stay in the blob's torch [out,in] layout = the K-contiguous B operand of the GEMM.
+#include "../../include/pfhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "json_min.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+pfhip_status fail(pfhip_status st, const std::string& msg) {
+  g_err = msg;
+  return st;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return fail(PFHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    bytes = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  float* f() const { return static_cast<float*>(p); }
+  int* i() const { return static_cast<int*>(p); }
+};
+
+struct Tensor {
+  const float* d = nullptr;   // device
+  const float* h = nullptr;   // host (only valid during create)
+  std::vector<int> shape;
+  size_t n = 0;
+};
+
+struct Config {
+  int d_model = 512, n_head = 4, ffn = 2048, enc_layers = 50, dec_layers = 16, dec_ffn = 2048;
+  int kernel = 11, vocab = 8404, n_mels = 80, lfr_m = 7, lfr_n = 6, pred_residual = 0;
+  float cif_threshold = 1.0f, tail_threshold = 0.45f, smooth_factor = 1.0f, noise_threshold = 0.0f;
+  int sample_rate = 16000;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct ProfRec { int cls; hipEvent_t e0, e1; };
+
+}  // namespace
+
+struct pfhip_model {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  std::mutex mu;
+  Config cfg;
+  int feat_dim = 560, feat_pad = 576, vocab_pad = 8448;
+
+  float* d_blob = nullptr;
+  std::map<std::string, Tensor> t;
+  float* d_w0qkv = nullptr;     // enc.0.qkv.w K-padded to feat_pad
+  float* d_predconv = nullptr;  // [d][3*d] im2col order
+  // front-end tables
+  float* d_window = nullptr; double* d_tw = nullptr; int* d_mel_off = nullptr; int* d_mel_size = nullptr;
+  float* d_mel_w = nullptr; float* d_inv_ts = nullptr;
+
+  // workspace
+  Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
+  Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta;
+  void* h_meta = nullptr; size_t h_meta_cap = 0;     // pinned
+  int* h_counts = nullptr;                            // pinned [2*B]
+  size_t h_counts_cap = 0;
+
+  // state of the last forward
+  int B = 0, M = 0, ML = 0, maxT = 0, maxL = 0;
+  std::vector<int> T, row_off, n_fires, token_num, tok_off;
+  bool have_logp = false;
+  // device views into meta / dmeta
+  int *m_frame_off = nullptr, *m_nframes = nullptr, *m_row_off = nullptr, *m_len = nullptr,
+      *m_row_pos = nullptr, *m_row_len = nullptr;
+  int64_t* m_sample_off = nullptr;
+  int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  pfhip_profile prof{};
+  hipStream_t prof_stream = nullptr;
+
+  const Tensor& W(const std::string& n) const { return t.at(n); }
+};
+
+namespace {
+
+using pfhip::launch_gemm_f32;
+
+struct Scope {
+  pfhip_model* m; hipStream_t s; int cls; hipEvent_t e1 = nullptr;
+  Scope(pfhip_model* m_, hipStream_t s_, int cls_, double flops, double bytes) : m(m_), s(s_), cls(cls_) {
+    if (!m->prof_on) return;
+    if (m->ev_used + 2 > m->ev_pool.size()) {
+      for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; m->ev_pool.push_back(e); }
+    }
+    hipEvent_t e0 = m->ev_pool[m->ev_used++];
+    e1 = m->ev_pool[m->ev_used++];
+    (void)hipEventRecord(e0, s);
+    m->prof_recs.push_back({cls, e0, e1});
+    m->prof.flops[cls] += flops;
+    m->prof.bytes[cls] += bytes;
+    m->prof.launches[cls] += 1;
+  }
+  ~Scope() { if (e1) (void)hipEventRecord(e1, s); }
+};
+
+enum { K_GEMM = 0, K_ATTN = 1, K_LN = 2, K_FSMN = 3, K_FBANK = 4, K_CIF = 5, K_HEAD = 6, K_OTHER = 7 };
+
+void gemm(pfhip_model* m, hipStream_t s, const float* A, int lda, const float* Wd, int N, int K, int Ktrue,
+          float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+          int M, bool relu) {
+  Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * Ktrue, 4.0 * ((double)M * Ktrue + (double)N * Ktrue + (double)M * N));
+  launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
+}
+void lnorm(pfhip_model* m, hipStream_t s, const float* x, int ldx, float* y, int ldy, const std::string& name,
+           int M, int D, int Dout) {
+  Scope sc(m, s, K_LN, 8.0 * M * D, 8.0 * M * D);
+  pfhip::launch_layernorm(x, ldx, y, ldy, m->W(name + ".g").d, m->W(name + ".b").d, M, D, Dout, 1e-12f, s);
+}
+
+// ---- front-end tables, computed exactly like knf does on the host --------------------------------
+void build_mel(int num_bins, float sample_freq, std::vector<int>& off, std::vector<int>& size,
+               std::vector<float>& w) {
+  // knf mel-computations.cc:107-196 with vtln_warp = 1, low 20 Hz, high = Nyquist (mel-computations.h:33-37)
+  auto mel_scale = [](float f) { return 1127.0f * logf(1.0f + f / 700.0f); };
+  const int padded = 512, num_fft_bins = padded / 2;
+  const float nyquist = 0.5f * sample_freq;
+  const float low_freq = 20.f, high_freq = nyquist + 0.f;
+  const float fft_bin_width = sample_freq / padded;
+  const float mel_low = mel_scale(low_freq), mel_high = mel_scale(high_freq);
+  const float delta = (mel_high - mel_low) / (num_bins + 1);
+  off.assign(num_bins, 0); size.assign(num_bins, 0); w.assign((size_t)num_bins * pfhip::kMelW, 0.f);
+  for (int bin = 0; bin < num_bins; ++bin) {
+    const float left = mel_low + bin * delta, center = mel_low + (bin + 1) * delta,
+                right = mel_low + (bin + 2) * delta;
+    int first = -1, last = -1;
+    std::vector<float> tb(num_fft_bins, 0.f);
+    for (int i = 0; i < num_fft_bins; ++i) {
+      const float freq = fft_bin_width * i;
+      const float mel = mel_scale(freq);
+      if (mel > left && mel < right) {
+        float weight;
+        if (mel <= center) weight = (mel - left) / (center - left);
+        else weight = (right - mel) / (right - center);
+        tb[i] = weight;
+        if (first == -1) first = i;
+        last = i;
+      }
+    }
+    off[bin] = first;
+    size[bin] = last + 1 - first;
+    for (int k = 0; k < size[bin] && k < pfhip::kMelW; ++k) w[(size_t)bin * pfhip::kMelW + k] = tb[first + k];
+  }
+}
+
+template <typename T>
+pfhip_status upload(T** dst, const std::vector<T>& v) {
+  HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PFHIP_OK;
+}
+
+pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
+                         pfhip_model** out) {
+  if (!blob || !manifest_json || !out) return fail(PFHIP_ERR_ARG, "null argument");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(PFHIP_ERR_ARG, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  pfhip::JValue man;
+  try { man = pfhip::JParser(manifest_json).parse(); }
+  catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
+  const pfhip::JValue* jc = man.get("config");
+  const pfhip::JValue* jt = man.get("tensors");
+  if (!jc || !jt || jt->kind != pfhip::JValue::OBJ) return fail(PFHIP_ERR_FORMAT, "manifest needs config and tensors");
+
+  std::unique_ptr<pfhip_model> m(new pfhip_model);
+  m->device = device;
+  Config& c = m->cfg;
+  c.d_model = (int)jc->number("d_model", c.d_model);
+  c.n_head = (int)jc->number("n_head", c.n_head);
+  c.ffn = (int)jc->number("ffn", c.ffn);
+  c.enc_layers = (int)jc->number("enc_layers", c.enc_layers);
+  c.dec_layers = (int)jc->number("dec_layers", c.dec_layers);
+  c.dec_ffn = (int)jc->number("dec_ffn", c.dec_ffn);
+  c.kernel = (int)jc->number("kernel", c.kernel);
+  c.vocab = (int)jc->number("vocab", c.vocab);
+  c.n_mels = (int)jc->number("n_mels", c.n_mels);
+  c.lfr_m = (int)jc->number("lfr_m", c.lfr_m);
+  c.lfr_n = (int)jc->number("lfr_n", c.lfr_n);
+  c.pred_residual = (int)jc->number("pred_residual", 0);
+  c.cif_threshold = (float)jc->number("cif_threshold", c.cif_threshold);
+  c.tail_threshold = (float)jc->number("tail_threshold", c.tail_threshold);
+  c.smooth_factor = (float)jc->number("smooth_factor", c.smooth_factor);
+  c.noise_threshold = (float)jc->number("noise_threshold", c.noise_threshold);
+
+  // what the gfx950 kernels are specialised for
+  if (c.d_model % 128 || c.d_model / c.n_head != pfhip::kHeadDim)
+    return fail(PFHIP_ERR_UNSUPPORTED, "attention kernel needs d_model/n_head == 128");
+  if (c.d_model > 1024) return fail(PFHIP_ERR_UNSUPPORTED, "d_model > 1024");
+  if (c.kernel != 11) return fail(PFHIP_ERR_UNSUPPORTED, "FSMN kernel size must be 11");
+  if (c.n_mels != 80 || c.lfr_m != 7 || c.lfr_n != 6) return fail(PFHIP_ERR_UNSUPPORTED, "front end needs 80 mels, LFR 7/6");
+  if (c.ffn % 128 || c.dec_ffn % 128 || c.ffn > 2048 || c.dec_ffn > 2048)
+    return fail(PFHIP_ERR_UNSUPPORTED, "ffn width must be a multiple of 128 and <= 2048");
+  if (c.enc_layers < 1 || c.dec_layers < 0) return fail(PFHIP_ERR_FORMAT, "bad layer counts");
+  m->feat_dim = c.n_mels * c.lfr_m;
+  m->feat_pad = round_up(m->feat_dim, pfhip::kTileK);
+  m->vocab_pad = round_up(c.vocab, pfhip::kTileN);
+
+  // ---- weights: upload the blob once; GEMM N-padding reads run into the slack at the end ----------
+  const size_t slack = (size_t)pfhip::kTileN * 2048 * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&m->d_blob, blob_bytes + slack));
+  HIP_TRY(hipMemset(m->d_blob, 0, blob_bytes + slack));
+  HIP_TRY(hipMemcpy(m->d_blob, blob, blob_bytes, hipMemcpyHostToDevice));
+  const float* hb = static_cast<const float*>(blob);
+  for (const auto& kv : jt->obj) {
+    const pfhip::JValue* sh = kv.second.get("shape");
+    const pfhip::JValue* of = kv.second.get("offset");
+    if (!sh || !of || sh->kind != pfhip::JValue::ARR) return fail(PFHIP_ERR_FORMAT, "tensor " + kv.first + ": shape/offset");
+    Tensor tt;
+    tt.n = 1;
+    for (const auto& d : sh->arr) { tt.shape.push_back((int)d.num); tt.n *= (size_t)d.num; }
+    const size_t off = (size_t)of->num;
+    if (off % 16 || off + tt.n * 4 > blob_bytes) return fail(PFHIP_ERR_FORMAT, "tensor " + kv.first + ": out of blob");
+    tt.d = m->d_blob + off / 4;
+    tt.h = hb + off / 4;
+    m->t.emplace(kv.first, std::move(tt));
+  }
+  // required tensors / shapes
+  auto need = [&](const std::string& n, std::vector<int> shape) -> bool {
+    auto it = m->t.find(n);
+    if (it == m->t.end()) { g_err = "missing tensor " + n; return false; }
+    if (it->second.shape != shape) { g_err = "tensor " + n + " has unexpected shape"; return false; }
+    return true;
+  };
+  const int d = c.d_model;
+  bool ok = need("cmvn.mean", {m->feat_dim}) && need("cmvn.istd", {m->feat_dim});
+  for (int i = 0; ok && i < c.enc_layers; ++i) {
+    const std::string p = "enc." + std::to_string(i) + ".";
+    const int in = i == 0 ? m->feat_dim : d;
+    ok = need(p + "norm1.g", {in}) && need(p + "norm1.b", {in}) && need(p + "qkv.w", {3 * d, in}) &&
+         need(p + "qkv.b", {3 * d}) && need(p + "fsmn.w", {d, c.kernel}) && need(p + "out.w", {d, d}) &&
+         need(p + "out.b", {d}) && need(p + "norm2.g", {d}) && need(p + "norm2.b", {d}) &&
+         need(p + "ffn1.w", {c.ffn, d}) && need(p + "ffn1.b", {c.ffn}) && need(p + "ffn2.w", {d, c.ffn}) &&
+         need(p + "ffn2.b", {d});
+  }
+  ok = ok && need("enc.after_norm.g", {d}) && need("enc.after_norm.b", {d}) && need("pred.conv.w", {d, d, 3}) &&
+       need("pred.conv.b", {d}) && need("pred.out.w", {1, d}) && need("pred.out.b", {1});
+  auto need_ffn = [&](const std::string& p) {
+    return need(p + "norm1.g", {d}) && need(p + "norm1.b", {d}) && need(p + "ffn1.w", {c.dec_ffn, d}) &&
+           need(p + "ffn1.b", {c.dec_ffn}) && need(p + "ffn_norm.g", {c.dec_ffn}) &&
+           need(p + "ffn_norm.b", {c.dec_ffn}) && need(p + "ffn2.w", {d, c.dec_ffn});
+  };
+  for (int i = 0; ok && i < c.dec_layers; ++i) {
+    const std::string p = "dec." + std::to_string(i) + ".";
+    ok = need_ffn(p) && need(p + "norm2.g", {d}) && need(p + "norm2.b", {d}) && need(p + "fsmn.w", {d, c.kernel}) &&
+         need(p + "norm3.g", {d}) && need(p + "norm3.b", {d}) && need(p + "q.w", {d, d}) && need(p + "q.b", {d}) &&
+         need(p + "kv.w", {2 * d, d}) && need(p + "kv.b", {2 * d}) && need(p + "out.w", {d, d}) && need(p + "out.b", {d});
+  }
+  ok = ok && need_ffn("dec3.") && need("dec.after_norm.g", {d}) && need("dec.after_norm.b", {d}) &&
+       need("dec.out.w", {c.vocab, d}) && need("dec.out.b", {c.vocab});
+  if (!ok) return PFHIP_ERR_FORMAT;
+
+  // ---- repacks ---------------------------------------------------------------------------------------
+  {
+    const Tensor& w0 = m->W("enc.0.qkv.w");
+    std::vector<float> p((size_t)3 * d * m->feat_pad, 0.f);
+    for (int n = 0; n < 3 * d; ++n)
+      std::memcpy(&p[(size_t)n * m->feat_pad], w0.h + (size_t)n * m->feat_dim, sizeof(float) * m->feat_dim);
+    pfhip_status st = upload(&m->d_w0qkv, p);
+    if (st) return st;
+    const Tensor& cw = m->W("pred.conv.w");
+    std::vector<float> q((size_t)d * 3 * d);
+    for (int n = 0; n < d; ++n)
+      for (int ci = 0; ci < d; ++ci)
+        for (int j = 0; j < 3; ++j) q[(size_t)n * 3 * d + (size_t)j * d + ci] = cw.h[((size_t)n * d + ci) * 3 + j];
+    st = upload(&m->d_predconv, q);
+    if (st) return st;
+  }
+  // ---- front-end tables ------------------------------------------------------------------------------
+  {
+    std::vector<float> win(400);
+    const double a = 2.0 * M_PI / (400 - 1);                       // feature-window.cc:33-42
+    for (int i = 0; i < 400; ++i) win[i] = (float)(0.54 - 0.46 * cos(a * (double)i));
+    std::vector<double> tw(512);
+    for (int k = 0; k < 256; ++k) { tw[2 * k] = cos(2.0 * M_PI * k / 512.0); tw[2 * k + 1] = -sin(2.0 * M_PI * k / 512.0); }
+    std::vector<int> moff, msz; std::vector<float> mw;
+    build_mel(c.n_mels, (float)c.sample_rate, moff, msz, mw);
+    for (int b = 0; b < c.n_mels; ++b)
+      if (msz[b] > pfhip::kMelW) return fail(PFHIP_ERR_UNSUPPORTED, "mel triangle wider than kMelW");
+    const int half = m->feat_dim / 2;
+    std::vector<float> inv(half);
+    // paraformer-online.cpp:247-252: float scale, exp() in double of a float argument, stored to float
+    const float scale = m->feat_dim == 560 ? -0.0330119726594128f : (float)(-std::log(10000.0) / (half - 1));
+    for (int i = 0; i < half; ++i) inv[i] = (float)exp((double)(i * scale));
+    pfhip_status st;
+    if ((st = upload(&m->d_window, win)) || (st = upload(&m->d_tw, tw)) || (st = upload(&m->d_mel_off, moff)) ||
+        (st = upload(&m->d_mel_size, msz)) || (st = upload(&m->d_mel_w, mw)) || (st = upload(&m->d_inv_ts, inv)))
+      return st;
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  for (auto& kv : m->t) kv.second.h = nullptr;
+  *out = m.release();
+  return PFHIP_OK;
+}
+
+pfhip_status read_file(const char* path, std::vector<char>& out) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) return fail(PFHIP_ERR_ARG, std::string("cannot open ") + path);
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  out.resize((size_t)n);
+  if (n && !f.read(out.data(), n)) return fail(PFHIP_ERR_ARG, std::string("cannot read ") + path);
+  return PFHIP_OK;
+}
+
+// ---- the forward ---------------------------------------------------------------------------------------
+pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* sample_off, const int* n_samples,
+                            int B, hipStream_t s, bool feats_only) {
+  const Config& c = m->cfg;
+  const int d = c.d_model, FD = m->feat_dim, FP = m->feat_pad;
+  HIP_TRY(hipSetDevice(m->device));
+  m->B = B; m->M = 0; m->ML = 0; m->maxT = 0; m->maxL = 0; m->have_logp = false;
+  m->T.assign(B, 0); m->row_off.assign(B, 0); m->n_fires.assign(B, 0); m->token_num.assign(B, 0); m->tok_off.assign(B, 0);
+  std::vector<int> F(B), frame_off(B + 1, 0);
+  for (int b = 0; b < B; ++b) {
+    if (n_samples[b] < 0) return fail(PFHIP_ERR_ARG, "negative sample count");
+    F[b] = n_samples[b] < 400 ? 0 : 1 + (n_samples[b] - 400) / 160;        // feature-window.cc:84-87
+    m->T[b] = (F[b] + c.lfr_n - 1) / c.lfr_n;                               // paraformer.cpp:425
+    m->row_off[b] = m->M;
+    m->M += m->T[b];
+    m->maxT = std::max(m->maxT, m->T[b]);
+    frame_off[b + 1] = frame_off[b] + F[b];
+  }
+  const int M = m->M, total_frames = frame_off[B];
+  if (M == 0) return PFHIP_OK;
+  const int Mp = round_up(M, pfhip::kTileM);
+
+  // ---- metadata: one pinned staging buffer, one H2D copy ---------------------------------------------
+  const size_t n_ints = (size_t)2 * B /*sample_off as int64*/ + (B + 1) + 3 * (size_t)B + 2 * (size_t)M + 8;
+  if (n_ints * 4 > m->h_meta_cap) {
+    if (m->h_meta) HIP_TRY(hipHostFree(m->h_meta));
+    m->h_meta = nullptr; m->h_meta_cap = 0;
+    HIP_TRY(hipHostMalloc(&m->h_meta, n_ints * 4 * 2, hipHostMallocDefault));
+    m->h_meta_cap = n_ints * 4 * 2;
+  }
+  HIP_TRY(m->meta.ensure(n_ints * 4));
+  {
+    int* hm = static_cast<int*>(m->h_meta);
+    int* dm = m->meta.i();
+    size_t o = 0;
+    std::memcpy(hm + o, sample_off, sizeof(int64_t) * B); m->m_sample_off = reinterpret_cast<int64_t*>(dm + o); o += 2 * (size_t)B;
+    std::memcpy(hm + o, frame_off.data(), 4 * (B + 1)); m->m_frame_off = dm + o; o += B + 1;
+    std::memcpy(hm + o, F.data(), 4 * B); m->m_nframes = dm + o; o += B;
+    std::memcpy(hm + o, m->row_off.data(), 4 * B); m->m_row_off = dm + o; o += B;
+    std::memcpy(hm + o, m->T.data(), 4 * B); m->m_len = dm + o; o += B;
+    if (o & 1) ++o;
+    m->m_row_pos = dm + o;
+    for (int b = 0; b < B; ++b) for (int t = 0; t < m->T[b]; ++t) hm[o + m->row_off[b] + t] = t;
+    o += M;
+    m->m_row_len = dm + o;
+    for (int b = 0; b < B; ++b) for (int t = 0; t < m->T[b]; ++t) hm[o + m->row_off[b] + t] = m->T[b];
+    o += M;
+    HIP_TRY(hipMemcpyAsync(dm, hm, o * 4, hipMemcpyHostToDevice, s));
+  }
+
+  // ---- workspace ---------------------------------------------------------------------------------------
+  HIP_TRY(m->feats.ensure((size_t)Mp * FD * 4));
+  if (!feats_only) {
+    HIP_TRY(m->x0.ensure((size_t)Mp * FP * 4));
+    HIP_TRY(m->x.ensure((size_t)Mp * d * 4));
+    HIP_TRY(m->y.ensure((size_t)Mp * FP * 4));
+    HIP_TRY(m->qkv.ensure((size_t)Mp * 3 * d * 4));
+    HIP_TRY(m->mem.ensure((size_t)Mp * d * 4));
+    HIP_TRY(m->ctx.ensure((size_t)Mp * d * 4));
+    HIP_TRY(m->hbuf.ensure((size_t)(Mp + B + 128) * std::max(c.ffn, d) * 4));
+    HIP_TRY(m->enc.ensure((size_t)Mp * d * 4));
+    HIP_TRY(m->alphas.ensure((size_t)Mp * 4));
+    HIP_TRY(m->counts.ensure((size_t)2 * B * 4));
+    if ((size_t)2 * B * 4 > m->h_counts_cap) {
+      if (m->h_counts) HIP_TRY(hipHostFree(m->h_counts));
+      m->h_counts = nullptr; m->h_counts_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&m->h_counts, (size_t)2 * B * 4 * 2, hipHostMallocDefault));
+      m->h_counts_cap = (size_t)2 * B * 4 * 2;
+    }
+  }
+
+  // ---- a2+a3: fbank -> LFR -> CMVN -----------------------------------------------------------------------
+  {
+    double in_bytes = 0;
+    for (int b = 0; b < B; ++b) in_bytes += 4.0 * n_samples[b];
+    Scope sc(m, s, K_FBANK, 0, in_bytes + 4.0 * FD * M);
+    pfhip::FbankTables tb{m->d_window, m->d_tw, m->d_mel_off, m->d_mel_size, m->d_mel_w,
+                          m->W("cmvn.mean").d, m->W("cmvn.istd").d};
+    pfhip::launch_fbank_lfr_cmvn(d_pcm, m->m_sample_off, m->m_frame_off, m->m_nframes, m->m_row_off, B,
+                                 total_frames, tb, m->feats.f(), s);
+  }
+  if (feats_only) { HIP_TRY(hipGetLastError()); return PFHIP_OK; }
+
+  // ---- a4: encoder -------------------------------------------------------------------------------------------
+  {
+    Scope sc(m, s, K_OTHER, 0, 4.0 * M * (FD + FP));
+    pfhip::launch_embed(m->feats.f(), FD, m->x0.f(), FP, m->m_row_pos, M, m->d_inv_ts, sqrtf((float)d), s);
+  }
+  const float att_scale = 1.0f / sqrtf((float)pfhip::kHeadDim);
+  double attn_pairs = 0;
+  for (int b = 0; b < B; ++b) attn_pairs += (double)m->T[b] * m->T[b];
+  float* x = m->x.f();
+  for (int i = 0; i < c.enc_layers; ++i) {
+    const std::string p = "enc." + std::to_string(i) + ".";
+    const bool first = i == 0;
+    const float* xin = first ? m->x0.f() : x;
+    const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
+    lnorm(m, s, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
+    gemm(m, s, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
+         m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
+    {
+      Scope sc(m, s, K_FSMN, 2.0 * 11 * M * d, 8.0 * M * d);
+      pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, m->m_row_off,
+                         m->m_len, B, m->maxT, d, s);
+    }
+    {
+      Scope sc(m, s, K_ATTN, 4.0 * attn_pairs * d, 16.0 * M * d);
+      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d,
+                              m->m_row_off, m->m_len, m->m_row_off, m->m_len, B, c.n_head, m->maxT, att_scale, s);
+    }
+    // x = (first ? 0 : x) + ctx*Wo + b + fsmn_memory
+    gemm(m, s, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
+         first ? nullptr : x, d, M, false);
+    lnorm(m, s, x, d, m->y.f(), d, p + "norm2", M, d, d);
+    gemm(m, s, m->y.f(), d, m->W(p + "ffn1.w").d, c.ffn, d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0,
+         nullptr, 0, M, true);
+    gemm(m, s, m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, d, c.ffn, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0,
+         M, false);
+  }
+  lnorm(m, s, x, d, m->enc.f(), d, "enc.after_norm", M, d, d);
+
+  // ---- predictor + CIF ------------------------------------------------------------------------------------
+  float* col = m->qkv.f();          // [Mp, 3d] reused
+  float* po = m->ctx.f();           // [Mp, d] reused
+  {
+    Scope sc(m, s, K_OTHER, 0, 16.0 * M * d);
+    pfhip::launch_im2col3(m->enc.f(), d, col, 3 * d, m->m_row_pos, m->m_row_len, M, d, s);
+  }
+  gemm(m, s, col, 3 * d, m->d_predconv, d, 3 * d, 3 * d, po, d, m->W("pred.conv.b").d,
+       c.pred_residual ? m->enc.f() : nullptr, d, nullptr, 0, M, true);
+  {
+    Scope sc(m, s, K_OTHER, 2.0 * M * d, 4.0 * M * d);
+    pfhip::launch_alpha(po, d, m->W("pred.out.w").d, m->W("pred.out.b").d, c.smooth_factor, c.noise_threshold,
+                        m->alphas.f(), M, d, s);
+  }
+  float* stage = m->hbuf.f();       // [(M+B), d] reused
+  {
+    Scope sc(m, s, K_CIF, 2.0 * M * d, 4.0 * M * d);
+    pfhip::launch_cif(m->enc.f(), d, m->alphas.f(), m->m_row_off, m->m_len, B, d, c.cif_threshold, c.tail_threshold,
+                      stage, m->counts.i(), m->counts.i() + B, s);
+  }
+  HIP_TRY(hipMemcpyAsync(m->h_counts, m->counts.p, (size_t)2 * B * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));      // the one host sync: token counts size the decoder launch
+  int ML = 0;
+  for (int b = 0; b < B; ++b) {
+    m->n_fires[b] = m->h_counts[b];
+    m->token_num[b] = m->h_counts[B + b];
+    m->tok_off[b] = ML;
+    ML += m->n_fires[b];
+    m->maxL = std::max(m->maxL, m->n_fires[b]);
+  }
+  m->ML = ML;
+  if (ML == 0) { HIP_TRY(hipGetLastError()); return PFHIP_OK; }
+  const int MLp = round_up(ML, pfhip::kTileM);
+
+  // ---- decoder-side metadata + workspace -------------------------------------------------------------
+  {
+    const size_t n = 2 * (size_t)B + ML;
+    HIP_TRY(m->dmeta.ensure(n * 4));
+    // second half of the pinned staging buffer: never overwritten while an earlier copy may be in flight
+    if (m->h_meta_cap / 2 + n * 4 > m->h_meta_cap) return fail(PFHIP_ERR_CAPACITY, "internal: metadata staging too small");
+    int* hm = reinterpret_cast<int*>(static_cast<char*>(m->h_meta) + m->h_meta_cap / 2);
+    int* dm = m->dmeta.i();
+    std::memcpy(hm, m->tok_off.data(), 4 * B); m->m_tok_off = dm;
+    std::memcpy(hm + B, m->n_fires.data(), 4 * B); m->m_tok_len = dm + B;
+    m->m_src_row = dm + 2 * B;
+    for (int b = 0; b < B; ++b)
+      for (int n2 = 0; n2 < m->n_fires[b]; ++n2) hm[2 * B + m->tok_off[b] + n2] = m->row_off[b] + b + n2;
+    HIP_TRY(hipMemcpyAsync(dm, hm, n * 4, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(m->emb.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->xd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->yd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->hd.ensure((size_t)MLp * c.dec_ffn * 4));
+  HIP_TRY(m->hd2.ensure((size_t)MLp * c.dec_ffn * 4));
+  HIP_TRY(m->td.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->t2.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->qd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->ctxd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->logits.ensure((size_t)MLp * m->vocab_pad * 4));
+  HIP_TRY(m->ids.ensure((size_t)MLp * 4));
+  {
+    Scope sc(m, s, K_OTHER, 0, 8.0 * ML * d);
+    pfhip::launch_compact(stage, m->emb.f(), m->m_src_row, ML, d, s);
+    HIP_TRY(hipMemcpyAsync(m->xd.p, m->emb.p, (size_t)ML * d * 4, hipMemcpyDeviceToDevice, s));
+  }
+
+  // ---- decoder ----------------------------------------------------------------------------------------------
+  float* xd = m->xd.f();
+  float* kvbuf = m->qkv.f();        // [Mp, 2d] reused
+  double cross_pairs = 0;
+  for (int b = 0; b < B; ++b) cross_pairs += (double)m->n_fires[b] * m->T[b];
+  auto dec_ffn = [&](const std::string& p, const float* xin, float* out) {
+    lnorm(m, s, xin, d, m->yd.f(), d, p + "norm1", ML, d, d);
+    gemm(m, s, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
+         0, nullptr, 0, ML, true);
+    lnorm(m, s, m->hd.f(), c.dec_ffn, m->hd2.f(), c.dec_ffn, p + "ffn_norm", ML, c.dec_ffn, c.dec_ffn);
+    gemm(m, s, m->hd2.f(), c.dec_ffn, m->W(p + "ffn2.w").d, d, c.dec_ffn, c.dec_ffn, out, d, nullptr, nullptr, 0, nullptr,
+         0, ML, false);
+  };
+  for (int i = 0; i < c.dec_layers; ++i) {
+    const std::string p = "dec." + std::to_string(i) + ".";
+    dec_ffn(p, xd, m->td.f());
+    lnorm(m, s, m->td.f(), d, m->t2.f(), d, p + "norm2", ML, d, d);
+    {
+      Scope sc(m, s, K_FSMN, 2.0 * 11 * ML * d, 12.0 * ML * d);
+      pfhip::launch_fsmn(m->t2.f(), d, m->W(p + "fsmn.w").d, xd, d, xd, d, m->m_tok_off, m->m_tok_len, B, m->maxL, d, s);
+    }
+    lnorm(m, s, xd, d, m->yd.f(), d, p + "norm3", ML, d, d);
+    gemm(m, s, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, ML, false);
+    gemm(m, s, m->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, M,
+         false);
+    {
+      Scope sc(m, s, K_ATTN, 4.0 * cross_pairs * d, 8.0 * ML * d + 8.0 * M * d);
+      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
+                              m->m_row_off, m->m_len, B, c.n_head, m->maxL, att_scale, s);
+    }
+    gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
+  }
+  dec_ffn("dec3.", xd, m->td.f());
+  lnorm(m, s, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
+  gemm(m, s, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->W("dec.out.b").d, nullptr, 0,
+       nullptr, 0, ML, false);
+  HIP_TRY(hipGetLastError());
+  return PFHIP_OK;
+}
+
+pfhip_status head_locked(pfhip_model* m, hipStream_t s, bool want_logp) {
+  if (m->ML == 0) return PFHIP_OK;
+  const int V = m->cfg.vocab;
+  if (want_logp) HIP_TRY(m->logp.ensure((size_t)m->ML * V * 4));
+  {
+    Scope sc(m, s, K_HEAD, 0, 4.0 * m->ML * V * (want_logp ? 3 : 2));
+    pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, m->ML, V, want_logp ? m->logp.f() : nullptr,
+                                    static_cast<int32_t*>(m->ids.p), s);
+  }
+  m->have_logp = want_logp;
+  HIP_TRY(hipGetLastError());
+  return PFHIP_OK;
+}
+
+pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
+  if (!out) return fail(PFHIP_ERR_ARG, "null out");
+  const int B = m->B;
+  for (int b = 0; b < B; ++b) {
+    if (out->token_num) out->token_num[b] = m->token_num[b];
+    if (out->n_fires) out->n_fires[b] = m->n_fires[b];
+    if (out->n_frames) out->n_frames[b] = m->T[b];
+  }
+  if (m->ML == 0) return PFHIP_OK;
+  if ((out->token_ids || out->logp) && out->max_tokens < m->maxL)
+    return fail(PFHIP_ERR_CAPACITY, "max_tokens smaller than the longest token sequence");
+  if (out->logp && !m->have_logp) {
+    pfhip_status st = head_locked(m, s, true);
+    if (st) return st;
+  }
+  std::vector<int32_t> ids;
+  if (out->token_ids) {
+    ids.resize(m->ML);
+    HIP_TRY(hipMemcpyAsync(ids.data(), m->ids.p, (size_t)m->ML * 4, hipMemcpyDeviceToHost, s));
+  }
+  const int V = m->cfg.vocab;
+  if (out->logp) {
+    for (int b = 0; b < B; ++b)
+      if (m->n_fires[b])
+        HIP_TRY(hipMemcpyAsync(out->logp + (size_t)b * out->max_tokens * V, m->logp.f() + (size_t)m->tok_off[b] * V,
+                               (size_t)m->n_fires[b] * V * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (out->token_ids)
+    for (int b = 0; b < B; ++b)
+      std::memcpy(out->token_ids + (size_t)b * out->max_tokens, ids.data() + m->tok_off[b], 4 * (size_t)m->n_fires[b]);
+  return PFHIP_OK;
+}
+
+pfhip_status stage_pcm(pfhip_model* m, const float* const* pcm, const int* n_samples, int B, hipStream_t s,
+                       std::vector<int64_t>& off) {
+  off.assign(B, 0);
+  int64_t tot = 0;
+  for (int b = 0; b < B; ++b) {
+    if (n_samples[b] < 0 || (n_samples[b] > 0 && !pcm[b])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
+    off[b] = tot;
+    tot += (n_samples[b] + 3) & ~3;
+  }
+  HIP_TRY(m->pcm.ensure((size_t)std::max<int64_t>(tot, 4) * 4));
+  for (int b = 0; b < B; ++b)
+    if (n_samples[b])
+      HIP_TRY(hipMemcpyAsync(m->pcm.f() + off[b], pcm[b], (size_t)n_samples[b] * 4, hipMemcpyHostToDevice, s));
+  return PFHIP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* pfhip_last_error(void) { return g_err.c_str(); }
+
+pfhip_status pfhip_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
+                                      pfhip_model** out) {
+  g_err.clear();
+  try { return build_model(blob, blob_bytes, manifest_json, device, out); }
+  catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
+}
+
+pfhip_status pfhip_create(const char* weight_blob_path, const char* manifest_json_path, int device, pfhip_model** out) {
+  g_err.clear();
+  if (!weight_blob_path || !manifest_json_path || !out) return fail(PFHIP_ERR_ARG, "null argument");
+  std::vector<char> blob, man;
+  pfhip_status st = read_file(weight_blob_path, blob);
+  if (st) return st;
+  st = read_file(manifest_json_path, man);
+  if (st) return st;
+  man.push_back('\0');
+  return pfhip_create_from_memory(blob.data(), blob.size(), man.data(), device, out);
+}
+
+void pfhip_destroy(pfhip_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
+                 &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
+                 &m->logits, &m->logp, &m->ids, &m->dmeta})
+    b->release();
+  for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_window, (void*)m->d_tw,
+                  (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts})
+    if (p) (void)hipFree(p);
+  if (m->h_meta) (void)hipHostFree(m->h_meta);
+  if (m->h_counts) (void)hipHostFree(m->h_counts);
+  for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  delete m;
+}
+
+int pfhip_sample_rate(const pfhip_model* m) { return m ? m->cfg.sample_rate : 0; }
+int pfhip_vocab_size(const pfhip_model* m) { return m ? m->cfg.vocab : 0; }
+int pfhip_feat_dim(const pfhip_model* m) { return m ? m->feat_dim : 0; }
+int pfhip_d_model(const pfhip_model* m) { return m ? m->cfg.d_model : 0; }
+
+pfhip_status pfhip_offline_enqueue(pfhip_model* m, const float* d_pcm, const int64_t* sample_off, const int* n_samples,
+                                   int batch, void* stream) {
+  g_err.clear();
+  if (!m || !sample_off || !n_samples || batch <= 0) return fail(PFHIP_ERR_ARG, "bad argument");
+  if (!d_pcm) return fail(PFHIP_ERR_ARG, "null device pcm");
+  std::lock_guard<std::mutex> lk(m->mu);
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->own_stream;
+  m->prof_stream = s;
+  pfhip_status st = enqueue_locked(m, d_pcm, sample_off, n_samples, batch, s, false);
+  if (st) return st;
+  return head_locked(m, s, false);
+}
+
+pfhip_status pfhip_offline_fetch(pfhip_model* m, pfhip_out* out) {
+  g_err.clear();
+  if (!m) return fail(PFHIP_ERR_ARG, "null model");
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  return fetch_locked(m, out, m->prof_stream ? m->prof_stream : m->own_stream);
+}
+
+pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,
+                                   const float* hw_emb, int n_hotwords, pfhip_out* out) {
+  g_err.clear();
+  (void)hw_emb; (void)n_hotwords;   // plain (non-contextual) model ignores hw_emb: paraformer.cpp:515 use_hotword=false
+  if (!m || !pcm || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->own_stream;
+  m->prof_stream = s;
+  std::vector<int64_t> off;
+  pfhip_status st = stage_pcm(m, pcm, n_samples, batch, s, off);
+  if (st) return st;
+  st = enqueue_locked(m, m->pcm.f(), off.data(), n_samples, batch, s, false);
+  if (st) return st;
+  st = head_locked(m, s, out->logp != nullptr);
+  if (st) return st;
+  return fetch_locked(m, out, s);
+}
+
+pfhip_status pfhip_extract_feats(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,
+                                 float* feats_out, size_t feats_cap_floats, int32_t* n_frames_out) {
+  g_err.clear();
+  if (!m || !pcm || !n_samples || batch <= 0) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->own_stream;
+  m->prof_stream = s;
+  std::vector<int64_t> off;
+  pfhip_status st = stage_pcm(m, pcm, n_samples, batch, s, off);
+  if (st) return st;
+  st = enqueue_locked(m, m->pcm.f(), off.data(), n_samples, batch, s, true);
+  if (st) return st;
+  if (n_frames_out) for (int b = 0; b < batch; ++b) n_frames_out[b] = m->T[b];
+  const size_t n = (size_t)m->M * m->feat_dim;
+  if (feats_out) {
+    if (n > feats_cap_floats) return fail(PFHIP_ERR_CAPACITY, "feats_out too small");
+    if (n) HIP_TRY(hipMemcpyAsync(feats_out, m->feats.p, n * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return PFHIP_OK;
+}
+
+pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size_t cap_floats, size_t* n_out) {
+  g_err.clear();
+  if (!m || !name || !dst) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->prof_stream ? m->prof_stream : m->own_stream;
+  const std::string nm(name);
+  const void* src = nullptr;
+  size_t n = 0;
+  const int d = m->cfg.d_model;
+  if (nm == "feats") { src = m->feats.p; n = (size_t)m->M * m->feat_dim; }
+  else if (nm == "enc") { src = m->enc.p; n = (size_t)m->M * d; }
+  else if (nm == "alphas") { src = m->alphas.p; n = (size_t)m->M; }
+  else if (nm == "emb") { src = m->emb.p; n = (size_t)m->ML * d; }
+  else if (nm == "logp") {
+    if (m->ML && !m->have_logp) { pfhip_status st = head_locked(m, s, true); if (st) return st; }
+    src = m->logp.p; n = (size_t)m->ML * m->cfg.vocab;
+  } else return fail(PFHIP_ERR_ARG, "unknown tensor name " + nm);
+  if (n > cap_floats) return fail(PFHIP_ERR_CAPACITY, "dst too small");
+  if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out) *n_out = n;
+  return PFHIP_OK;
+}
+
+pfhip_status pfhip_profile_enable(pfhip_model* m, int on) {
+  if (!m) return fail(PFHIP_ERR_ARG, "null model");
+  std::lock_guard<std::mutex> lk(m->mu);
+  m->prof_on = on != 0;
+  return PFHIP_OK;
+}
+
+pfhip_status pfhip_profile_read(pfhip_model* m, pfhip_profile* out, int reset) {
+  g_err.clear();
+  if (!m || !out) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  if (m->prof_stream) HIP_TRY(hipStreamSynchronize(m->prof_stream));
+  for (const ProfRec& r : m->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) m->prof.ms[r.cls] += ms;
+  }
+  m->prof_recs.clear();
+  m->ev_used = 0;
+  *out = m->prof;
+  if (reset) m->prof = pfhip_profile{};
+  return PFHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+"""Weight container for the HIP Paraformer path + a seeded synthetic-weight generator.
+
+Container = one flat little-endian float32 blob + a JSON manifest
+    {"config": {...}, "tensors": {name: {"shape": [...], "offset": <bytes>}}}
+The file contract it stands in for is the reference's model directory
+(`model.onnx`, `am.mvn`, `config.yaml`; onnxruntime/include/com-define.h:52-73) — the real files are
+downloaded from ModelScope at server start (websocket/bin/funasr-wss-server.cpp:203-320) and are not
+available offline, so benchmarks and tests use random-init weights of the same architecture
+(SURVEY.md §8d "Synthetic inputs", appendix A for the tensor shapes).
+
+Linear weights are stored torch-style `[out, in]` (K contiguous), which is also the layout the MFMA
+GEMM kernels stream as their B operand.
+"""
+from __future__ import annotations
+
+import json
+import math
+
+import numpy as np
+
+ALIGN = 256  # bytes
+
+# Paraformer-large offline (in-tree corroboration paraformer.h:112-121)
+PARAFORMER_LARGE = dict(
+    d_model=512, n_head=4, ffn=2048, enc_layers=50, dec_layers=16, dec_ffn=2048, kernel=11,
+    vocab=8404, n_mels=80, lfr_m=7, lfr_n=6, cif_threshold=1.0, tail_threshold=0.45,
+    smooth_factor=1.0, noise_threshold=0.0, pred_residual=0,
+)
+
+
+def small_config(**over):
+    """Same widths as Paraformer-large (kernels are specialised for d_model 512 / d_k 128) but few
+    layers and a small ragged vocabulary, so the CPU oracle finishes in seconds."""
+    cfg = dict(PARAFORMER_LARGE)
+    cfg.update(enc_layers=3, dec_layers=2, vocab=1003)
+    cfg.update(over)
+    return cfg
+
+
+def tensor_specs(cfg):
+    """Ordered (name, shape, init) list. init: ('normal', std) | ('const', v)."""
+    d, f, fd, V, k = cfg["d_model"], cfg["ffn"], cfg["dec_ffn"], cfg["vocab"], cfg["kernel"]
+    feat = cfg["n_mels"] * cfg["lfr_m"]
+    specs = []
+
+    def lin(name, out_f, in_f, bias=True):
+        specs.append((name + ".w", [out_f, in_f], ("normal", 1.0 / math.sqrt(in_f))))
+        if bias:
+            specs.append((name + ".b", [out_f], ("normal", 0.02)))
+
+    def ln(name, n):
+        specs.append((name + ".g", [n], ("const", 1.0)))
+        specs.append((name + ".b", [n], ("const", 0.0)))
+
+    specs.append(("cmvn.mean", [feat], ("const", -8.0)))
+    specs.append(("cmvn.istd", [feat], ("const", 0.3)))
+    for i in range(cfg["enc_layers"]):
+        p = f"enc.{i}."
+        in_f = feat if i == 0 else d
+        ln(p + "norm1", in_f)
+        lin(p + "qkv", 3 * d, in_f)
+        specs.append((p + "fsmn.w", [d, k], ("normal", 1.0 / math.sqrt(k))))
+        lin(p + "out", d, d)
+        ln(p + "norm2", d)
+        lin(p + "ffn1", f, d)
+        lin(p + "ffn2", d, f)
+    ln("enc.after_norm", d)
+    specs.append(("pred.conv.w", [d, d, 3], ("normal", 1.0 / math.sqrt(3 * d))))
+    specs.append(("pred.conv.b", [d], ("normal", 0.02)))
+    # alphas ~ sigmoid(N(bias, ~0.6)): mean ~0.25 -> ~4 tokens per second of audio
+    specs.append(("pred.out.w", [1, d], ("normal", 1.0 / math.sqrt(d))))
+    specs.append(("pred.out.b", [1], ("const", -1.25)))
+    for i in range(cfg["dec_layers"]):
+        p = f"dec.{i}."
+        ln(p + "norm1", d)
+        lin(p + "ffn1", fd, d)
+        ln(p + "ffn_norm", fd)
+        lin(p + "ffn2", d, fd, bias=False)
+        ln(p + "norm2", d)
+        specs.append((p + "fsmn.w", [d, k], ("normal", 1.0 / math.sqrt(k))))
+        ln(p + "norm3", d)
+        lin(p + "q", d, d)
+        lin(p + "kv", 2 * d, d)
+        lin(p + "out", d, d)
+    ln("dec3.norm1", d)
+    lin("dec3.ffn1", fd, d)
+    ln("dec3.ffn_norm", fd)
+    lin("dec3.ffn2", d, fd, bias=False)
+    ln("dec.after_norm", d)
+    lin("dec.out", V, d)
+    return specs
+
+
+def build_manifest(cfg):
+    tensors = {}
+    off = 0
+    for name, shape, _ in tensor_specs(cfg):
+        n = int(np.prod(shape))
+        tensors[name] = {"shape": shape, "offset": off}
+        off += (n * 4 + ALIGN - 1) // ALIGN * ALIGN
+    return {"config": cfg, "tensors": tensors, "total_bytes": off}
+
+
+def synth_weights(cfg, seed=1234):
+    """Returns (manifest dict, float32 blob ndarray).  Seed 1234, N(0, 1/fan_in), LayerNorm gamma 1
+    beta 0 with a small seeded perturbation so that gamma/beta code paths are exercised."""
+    man = build_manifest(cfg)
+    blob = np.zeros(man["total_bytes"] // 4, np.float32)
+    rng = np.random.default_rng(seed)
+    for name, shape, init in tensor_specs(cfg):
+        n = int(np.prod(shape))
+        o = man["tensors"][name]["offset"] // 4
+        if init[0] == "normal":
+            blob[o:o + n] = rng.standard_normal(n, dtype=np.float32) * np.float32(init[1])
+        else:
+            blob[o:o + n] = np.float32(init[1])
+            if name.endswith(".g") or (name.endswith(".b") and "norm" in name):
+                blob[o:o + n] += rng.standard_normal(n, dtype=np.float32) * np.float32(0.05)
+    return man, blob
+
+
+def save(path_prefix, man, blob):
+    blob.tofile(path_prefix + ".bin")
+    with open(path_prefix + ".json", "w") as f:
+        json.dump(man, f)
+
+
+def load(path_prefix):
+    with open(path_prefix + ".json") as f:
+        man = json.load(f)
+    blob = np.fromfile(path_prefix + ".bin", dtype=np.float32)
+    return man, blob

@@ -1,0 +1,124 @@
+/*
+ * pfhip.h — plain-C ABI of the MI355X (gfx950) Paraformer acoustic-model forward path.
+ *
+ * This is the drop-in boundary beneath the reference's `funasr::Model` plug-in seam
+ * (onnxruntime/include/model.h:13-46).  Every entry point names the reference interface it replaces
+ * (paths relative to the reference root).  Plain C types only; no exceptions cross this boundary;
+ * every function returns a pfhip_status and pfhip_last_error() holds a thread-local message.
+ *
+ * Threading: like the reference's `Model::Forward`, which all decoder threads call concurrently on
+ * one shared handle (websocket/bin/funasr-wss-server.cpp:479-481), every entry point taking a
+ * pfhip_model* is re-entrant; calls are serialised on an internal per-model lock (one GPU, one
+ * workspace).
+ */
+#ifndef PFHIP_H_
+#define PFHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfhip_model pfhip_model;
+
+typedef enum {
+  PFHIP_OK = 0,
+  PFHIP_ERR_ARG = 1,         /* null / out-of-range argument                                   */
+  PFHIP_ERR_HIP = 2,         /* a HIP runtime call failed (message has hipGetErrorString)      */
+  PFHIP_ERR_FORMAT = 3,      /* manifest / blob malformed or tensor missing                    */
+  PFHIP_ERR_UNSUPPORTED = 4, /* configuration outside what the gfx950 kernels are built for    */
+  PFHIP_ERR_CAPACITY = 5     /* caller-provided output buffer too small                        */
+} pfhip_status;
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* pfhip_last_error(void);
+
+/* ---- model lifetime --------------------------------------------------------------------------
+ * Replaces Paraformer::InitAsr(am_model, am_cmvn, am_config, token_file, thread_num)
+ * (onnxruntime/src/paraformer.cpp:21-53): loads weights + CMVN + config and builds the fbank tables
+ * (knf options of paraformer.cpp:24-31).  Weight container: flat little-endian float32 blob + JSON
+ * manifest (see asr-2pass_amd/weights.py).  `device` is the HIP device ordinal (one model replica
+ * per GPU; SURVEY.md §8e "replicas only"). */
+pfhip_status pfhip_create(const char* weight_blob_path, const char* manifest_json_path, int device,
+                          pfhip_model** out);
+pfhip_status pfhip_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json,
+                                      int device, pfhip_model** out);
+/* Replaces Paraformer::~Paraformer (paraformer.cpp:267-295). */
+void pfhip_destroy(pfhip_model* m);
+
+/* Model facts the host adapter needs (Model::GetAsrSampleRate model.h:40; vocab size = logits width). */
+int pfhip_sample_rate(const pfhip_model* m);
+int pfhip_vocab_size(const pfhip_model* m);
+int pfhip_feat_dim(const pfhip_model* m);   /* lfr_m * n_mels (560) */
+int pfhip_d_model(const pfhip_model* m);
+
+/* ---- offline forward --------------------------------------------------------------------------
+ * Replaces the body of Paraformer::Forward / ParaformerTorch::Forward between `float** din` and the
+ * greedy token ids (onnxruntime/src/paraformer.cpp:463-589; batched contract
+ * onnxruntime/src/paraformer-torch.cpp:301-475): FbankKaldi (:309-323) -> LfrCmvn (:421-461) ->
+ * `m_session_->Run` (:541) -> GreedySearch/FindMax (:386-395, util.cpp:63-74).
+ *
+ * Caller-owned output buffers (any optional pointer may be NULL):
+ *   token_ids [batch*max_tokens]  argmax ids, row-major per utterance (first-max-wins)
+ *   token_num [batch]             floor(sum alphas) — the reference's outputTensor[1] (paraformer.cpp:547)
+ *   n_fires   [batch]             rows of log-probs the graph produced for the utterance (CIF fires)
+ *   n_frames  [batch]             LFR frames T (paraformer.cpp:483)
+ *   logp      [batch*max_tokens*vocab]  log-probs (only when a WFST decoder consumes them,
+ *                                 paraformer.cpp:563-579); rows >= n_fires are untouched
+ * An utterance shorter than one fbank window yields token_num = n_fires = 0 (paraformer.cpp:477-480).
+ */
+typedef struct {
+  int32_t* token_ids;
+  int32_t* token_num;
+  int32_t* n_fires;
+  int32_t* n_frames;
+  float* logp;
+  int32_t max_tokens;
+} pfhip_out;
+
+/* Host-buffer form: pcm[i] points at n_samples[i] floats in [-1,1) exactly as Model::Forward gets
+ * them from Audio::FetchDynamic (onnxruntime/src/audio.cpp:1052-1108).  Does H2D, the forward, D2H. */
+pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, const int* n_samples,
+                                   int batch, const float* hw_emb, int n_hotwords, pfhip_out* out);
+
+/* Device-resident form (what bench.py times): d_pcm is ONE device buffer holding the utterances
+ * back to back; sample_off/n_samples are host arrays.  All kernels are enqueued on `stream`
+ * (a hipStream_t, NULL = the model's own stream); results stay in the model's device workspace until
+ * pfhip_offline_fetch.  One host sync happens inside (the CIF token counts size the decoder launch). */
+pfhip_status pfhip_offline_enqueue(pfhip_model* m, const float* d_pcm, const int64_t* sample_off,
+                                   const int* n_samples, int batch, void* stream);
+pfhip_status pfhip_offline_fetch(pfhip_model* m, pfhip_out* out);
+
+/* ---- front end only ----------------------------------------------------------------------------
+ * Replaces Paraformer::FbankKaldi + LfrCmvn (paraformer.cpp:309-323, 421-461) on their own:
+ * feats_out gets sum(n_frames)*feat_dim floats, utterances back to back; n_frames_out [batch]. */
+pfhip_status pfhip_extract_feats(pfhip_model* m, const float* const* pcm, const int* n_samples,
+                                 int batch, float* feats_out, size_t feats_cap_floats,
+                                 int32_t* n_frames_out);
+
+/* ---- inspection (parity tests) -----------------------------------------------------------------
+ * Copies a named intermediate of the LAST forward to host: "feats" [M,560], "enc" [M,d],
+ * "alphas" [M] (without the tail slot), "emb" [sum fires, d], "logp" [sum fires, vocab].
+ * Rows are utterance-major in batch order.  *n_out = floats written. */
+pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size_t cap_floats,
+                              size_t* n_out);
+
+/* ---- per-kernel timing (bench.py roofline leg) -------------------------------------------------
+ * When enabled, each launch of a kernel class is bracketed by hipEvents on the launch stream.
+ * Classes: 0 gemm, 1 attention, 2 layernorm, 3 fsmn, 4 fbank, 5 cif, 6 head(log-softmax/argmax), 7 other. */
+#define PFHIP_NUM_KCLASS 8
+typedef struct {
+  double ms[PFHIP_NUM_KCLASS];       /* summed device time                                         */
+  int64_t launches[PFHIP_NUM_KCLASS];
+  double flops[PFHIP_NUM_KCLASS];    /* algorithmic flops issued (pad rows/cols excluded)           */
+  double bytes[PFHIP_NUM_KCLASS];    /* algorithmic bytes (compulsory reads + writes)               */
+} pfhip_profile;
+pfhip_status pfhip_profile_enable(pfhip_model* m, int on);
+pfhip_status pfhip_profile_read(pfhip_model* m, pfhip_profile* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFHIP_H_ */

@@ -1,0 +1,251 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+CPU (numpy fp32, BLAS-backed matmul) restatement of the Paraformer-large offline graph that the
+reference runs as one opaque `m_session_->Run` (onnxruntime/src/paraformer.cpp:541) plus the C++
+pieces around it:
+
+  a4  the ONNX graph (UPSTREAM FunASR export) — batch 1, as the reference
+      hard-wires (paraformer.cpp:470-473, 496-507)
+  a5  Paraformer::GreedySearch / FindMax      paraformer.cpp:386-408, util.cpp:63-74
+  a12 CIF integrate-and-fire recurrence       paraformer-online.cpp:306-327 (the reference's own C++
+      statement of the scan; the offline graph uses the same recurrence inside the ONNX file)
+
+PARITY UNPINNED for a4: the arithmetic of this span lives in onnxruntime 1.14.0 (absent:
+.MISSING_LARGE_BLOBS:7-8) applied to ModelScope weight files (absent), and the reference holds no
+fixture at this boundary.  What IS pinned in-tree and honoured here: tensor ranks /
+dtypes / order at the Run boundary (paraformer.cpp:496-562), d_model 512 / 16 decoder blocks / FSMN
+order 10 / CIF threshold 1.0 and tail 0.45 (paraformer.h:112-121), log-prob output consumed by
+argmax with first-max-wins (util.cpp:63-74).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import frontend
+
+F32 = np.float32
+LN_EPS = F32(1e-12)          # UPSTREAM ESPnet-style LayerNorm eps
+
+
+def layer_norm(x, g, b):
+    x = x.astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = (x - mu).astype(F32)
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + LN_EPS) * g + b).astype(F32)
+
+
+def linear(x, w, b=None):
+    """torch Linear: w is [out, in]."""
+    y = x.astype(F32) @ w.T.astype(F32)
+    if b is not None:
+        y = y + b
+    return y.astype(F32)
+
+
+def fsmn(v, w):
+    """Depthwise conv over time, kernel k, symmetric zero padding (k-1)/2, no bias, plus identity.
+    w: [d, k].  v: [T, d]."""
+    T, d = v.shape
+    k = w.shape[1]
+    lp = (k - 1) // 2
+    vp = np.zeros((T + k - 1, d), F32)
+    vp[lp:lp + T] = v
+    out = v.astype(F32).copy()
+    for j in range(k):
+        out += vp[j:j + T] * w[:, j][None, :]
+    return out.astype(F32)
+
+
+def softmax_rows(s):
+    m = s.max(axis=-1, keepdims=True)
+    e = np.exp((s - m).astype(F32)).astype(F32)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+
+
+def mha(q, k, v, n_head):
+    """q [Lq, d], k/v [Lk, d]; returns context [Lq, d] (before the output projection)."""
+    Lq, d = q.shape
+    dk = d // n_head
+    scale = F32(dk ** -0.5)
+    out = np.empty((Lq, d), F32)
+    for h in range(n_head):
+        sl = slice(h * dk, (h + 1) * dk)
+        s = ((q[:, sl] * scale).astype(F32) @ k[:, sl].T).astype(F32)
+        p = softmax_rows(s)
+        out[:, sl] = p @ v[:, sl]
+    return out
+
+
+class Weights:
+    """name -> float32 ndarray view over the flat blob described by the manifest."""
+
+    def __init__(self, manifest: dict, blob: np.ndarray):
+        self.cfg = manifest["config"]
+        self.t = {}
+        for name, meta in manifest["tensors"].items():
+            n = int(np.prod(meta["shape"])) if meta["shape"] else 1
+            off = meta["offset"] // 4
+            self.t[name] = blob[off:off + n].reshape(meta["shape"])
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+    def has(self, k):
+        return k in self.t
+
+
+def encoder_layer(x, W, pfx, n_head):
+    in_size = x.shape[1]
+    y = layer_norm(x, W[pfx + "norm1.g"], W[pfx + "norm1.b"])
+    qkv = linear(y, W[pfx + "qkv.w"], W[pfx + "qkv.b"])
+    d = qkv.shape[1] // 3
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    mem = fsmn(v, W[pfx + "fsmn.w"])
+    ctx = mha(q, k, v, n_head)
+    att = linear(ctx, W[pfx + "out.w"], W[pfx + "out.b"]) + mem
+    x = (x + att).astype(F32) if in_size == d else att.astype(F32)
+    y = layer_norm(x, W[pfx + "norm2.g"], W[pfx + "norm2.b"])
+    h = np.maximum(linear(y, W[pfx + "ffn1.w"], W[pfx + "ffn1.b"]), F32(0))
+    x = (x + linear(h, W[pfx + "ffn2.w"], W[pfx + "ffn2.b"])).astype(F32)
+    return x
+
+
+def embed(feats, d_model):
+    """x * sqrt(d_model) + PE(depth = feature dim), positions from 1 (paraformer-online.cpp:549-555,
+    240-268 state the same two steps for the streaming model)."""
+    T, D = feats.shape
+    return (feats * F32(math.sqrt(d_model)) + frontend.pos_emb(T, D)).astype(F32)
+
+
+def encoder(feats, W):
+    cfg = W.cfg
+    x = embed(feats, cfg["d_model"])
+    for i in range(cfg["enc_layers"]):
+        x = encoder_layer(x, W, f"enc.{i}.", cfg["n_head"])
+    return layer_norm(x, W["enc.after_norm.g"], W["enc.after_norm.b"])
+
+
+def predictor_alphas(enc, W):
+    """CifPredictorV2 (UPSTREAM): conv1d k=3 pad 1 -> (+residual if cfg) -> ReLU -> linear -> sigmoid ->
+    relu(a*smooth - noise); then the tail: one extra slot with tail_threshold and a zero hidden frame."""
+    cfg = W.cfg
+    T, d = enc.shape
+    cw = W["pred.conv.w"]            # [d_out, d_in, 3]
+    hp = np.zeros((T + 2, d), F32)
+    hp[1:T + 1] = enc
+    mem = np.zeros((T, d), F32)
+    for j in range(3):
+        mem += hp[j:j + T] @ cw[:, :, j].T
+    mem = (mem + W["pred.conv.b"]).astype(F32)
+    if cfg.get("pred_residual", 0):
+        mem = (mem + enc).astype(F32)
+    o = np.maximum(mem, F32(0))
+    logit = (o @ W["pred.out.w"].reshape(-1) + W["pred.out.b"].reshape(-1)[0]).astype(F32)
+    alphas = (F32(1) / (F32(1) + np.exp(-logit))).astype(F32)
+    alphas = np.maximum(alphas * F32(cfg.get("smooth_factor", 1.0)) - F32(cfg.get("noise_threshold", 0.0)), F32(0)).astype(F32)
+    alphas = np.concatenate([alphas, np.asarray([cfg["tail_threshold"]], F32)]).astype(F32)
+    hidden = np.concatenate([enc, np.zeros((1, d), F32)], axis=0)
+    return hidden, alphas
+
+
+def cif(hidden, alphas, threshold=1.0):
+    """The scalar recurrence exactly as ParaformerOnline::CifSearch states it
+    (paraformer-online.cpp:301-327), without the streaming cache handling."""
+    thr = F32(threshold)
+    integrate = F32(0.0)
+    frames = np.zeros(hidden.shape[1], F32)
+    out = []
+    fires = []
+    for i in range(alphas.shape[0]):
+        alpha = F32(alphas[i])
+        if F32(alpha + integrate) < thr:
+            integrate = F32(integrate + alpha)
+            fires.append(integrate)
+            frames = (frames + alpha * hidden[i]).astype(F32)
+        else:
+            frames = (frames + F32(thr - integrate) * hidden[i]).astype(F32)
+            out.append(frames.copy())
+            integrate = F32(integrate + alpha)
+            fires.append(integrate)
+            integrate = F32(integrate - thr)
+            frames = (integrate * hidden[i]).astype(F32)
+    emb = np.stack(out).astype(F32) if out else np.zeros((0, hidden.shape[1]), F32)
+    return emb, np.asarray(fires, F32)
+
+
+def decoder_ffn(x, W, pfx):
+    h = np.maximum(linear(x, W[pfx + "ffn1.w"], W[pfx + "ffn1.b"]), F32(0))
+    h = layer_norm(h, W[pfx + "ffn_norm.g"], W[pfx + "ffn_norm.b"])
+    return linear(h, W[pfx + "ffn2.w"])
+
+
+def decoder_layer(x, mem, W, pfx, n_head):
+    residual = x
+    t = decoder_ffn(layer_norm(x, W[pfx + "norm1.g"], W[pfx + "norm1.b"]), W, pfx)
+    t2 = layer_norm(t, W[pfx + "norm2.g"], W[pfx + "norm2.b"])
+    x = (residual + fsmn(t2, W[pfx + "fsmn.w"])).astype(F32)
+    residual = x
+    y = layer_norm(x, W[pfx + "norm3.g"], W[pfx + "norm3.b"])
+    q = linear(y, W[pfx + "q.w"], W[pfx + "q.b"])
+    kv = linear(mem, W[pfx + "kv.w"], W[pfx + "kv.b"])
+    d = q.shape[1]
+    ctx = mha(q, kv[:, :d], kv[:, d:], n_head)
+    x = (residual + linear(ctx, W[pfx + "out.w"], W[pfx + "out.b"])).astype(F32)
+    return x
+
+
+def decoder(emb, mem, W):
+    cfg = W.cfg
+    x = emb
+    for i in range(cfg["dec_layers"]):
+        x = decoder_layer(x, mem, W, f"dec.{i}.", cfg["n_head"])
+    # decoders3: FFN-only layer, NO residual (UPSTREAM DecoderLayerSANM with self_attn=src_attn=None)
+    x = decoder_ffn(layer_norm(x, W["dec3.norm1.g"], W["dec3.norm1.b"]), W, "dec3.")
+    x = layer_norm(x, W["dec.after_norm.g"], W["dec.after_norm.b"])
+    logits = linear(x, W["dec.out.w"], W["dec.out.b"])
+    m = logits.max(axis=-1, keepdims=True)
+    z = (logits - m).astype(F32)
+    lse = np.log(np.exp(z).sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    return (z - lse).astype(F32)
+
+
+def find_max(row):
+    """util.cpp:63-74 — strict '>' scan: first maximum wins; returns (val, idx)."""
+    idx = int(np.argmax(row))
+    return row[idx], idx
+
+
+def greedy_search(logp, n_len):
+    """paraformer.cpp:386-395 — argmax of the first n_len rows."""
+    return [find_max(logp[i])[1] for i in range(min(n_len, logp.shape[0]))]
+
+
+def forward_feats(feats, W, stages=None):
+    """feats [T, 560] -> dict(logp [L, V], token_num, alphas [T+1], enc [T, d], emb [L, d], ids)."""
+    enc = encoder(feats, W)
+    hidden, alphas = predictor_alphas(enc, W)
+    # token_num = floor(sum alphas); summed left-to-right in fp32 (the order the HIP scan uses; the
+    # ONNX ReduceSum order is unknowable here and only matters within 1e-5 of an integer)
+    token_num = int(math.floor(float(np.cumsum(alphas, dtype=F32)[-1])))
+    emb, fires = cif(hidden, alphas, W.cfg["cif_threshold"])
+    res = dict(enc=enc, alphas=alphas, token_num=token_num, emb=emb, fires=fires)
+    if emb.shape[0] > 0:
+        logp = decoder(emb, enc, W)
+    else:
+        logp = np.zeros((0, W.cfg["vocab"]), F32)
+    res["logp"] = logp
+    res["ids"] = greedy_search(logp, token_num)
+    return res
+
+
+def forward_pcm(waves, W):
+    """Model::Forward for one utterance: pcm [-1,1) float32 -> result dict (paraformer.cpp:463-589)."""
+    feats = frontend.extract_feats(waves, W["cmvn.mean"], W["cmvn.istd"])
+    if feats.shape[0] == 0:
+        return dict(feats=feats, logp=np.zeros((0, W.cfg["vocab"]), F32), token_num=0, ids=[])
+    r = forward_feats(feats, W)
+    r["feats"] = feats
+    return r

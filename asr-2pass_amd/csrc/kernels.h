@@ -34,10 +34,14 @@ void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_
 
 // ---- dense ops --------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) (+R1[M,N]) (+R2[M,N]) (ReLU)   — fp32 MFMA 32x32x2.
-// A rows must be allocated up to a multiple of 128, K % 32 == 0, W has ceil(N/128)*128 rows of K.
+// A rows must be allocated up to a multiple of 128, K % 32 == 0, W readable for ceil(N/128)*128 rows.
+// guard == false (the product path): C/R1/R2 are allocated for ceil(M/128)*128 rows and
+// ceil(N/128)*128 columns and bias is readable to the padded N, so the epilogue has no bounds
+// branches (pad outputs are junk nobody reads).  guard == true bounds-checks every element.
+// C may alias R1 or R2 (in-place residual update).
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
-                     int M, int N, int K, bool relu, hipStream_t s);
+                     int M, int N, int K, bool relu, bool guard, hipStream_t s);
 
 // y[row][0..D) = LN(x[row][0..D)) * g + b; columns D..Dout zeroed.  D % 4 == 0, Dout <= 2048.
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,

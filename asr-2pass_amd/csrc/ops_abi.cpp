@@ -1,0 +1,49 @@
+// Operator-level C ABI (include/pfhip_ops.h): thin wrappers over the kernel launchers.
+#include "../../include/pfhip_ops.h"
+
+#include "kernels.h"
+
+namespace {
+inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+inline int done() { return (int)hipGetLastError(); }
+}  // namespace
+
+extern "C" {
+
+int pfhip_op_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                      const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
+                      int guard, void* stream) {
+  if (K % pfhip::kTileK) return (int)hipErrorInvalidValue;
+  pfhip::launch_gemm_f32(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu != 0, guard != 0, S(stream));
+  return done();
+}
+int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
+                       int Dout, float eps, void* stream) {
+  if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;
+  pfhip::launch_layernorm(x, ldx, y, ldy, g, b, M, D, Dout, eps, S(stream));
+  return done();
+}
+int pfhip_op_fsmn(const float* v, int ldv, const float* w, const float* res, int ldres, float* out, int ldo,
+                  const int* off, const int* len, int B, int max_len, int C, void* stream) {
+  if (C % 4) return (int)hipErrorInvalidValue;
+  pfhip::launch_fsmn(v, ldv, w, res, ldres, out, ldo, off, len, B, max_len, C, S(stream));
+  return done();
+}
+int pfhip_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                       const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                       int max_q_len, float scale, void* stream) {
+  pfhip::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, S(stream));
+  return done();
+}
+int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
+                 float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream) {
+  if (D > 1024) return (int)hipErrorInvalidValue;
+  pfhip::launch_cif(hidden, ldh, alphas, row_off, len, B, D, threshold, tail, stage, n_fires, token_num, S(stream));
+  return done();
+}
+int pfhip_op_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids, void* stream) {
+  pfhip::launch_logsoftmax_argmax(logits, ldl, ML, V, logp, ids, S(stream));
+  return done();
+}
+
+}  // extern "C"

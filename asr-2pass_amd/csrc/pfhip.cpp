@@ -86,6 +86,7 @@ struct pfhip_model {
   std::map<std::string, Tensor> t;
   float* d_w0qkv = nullptr;     // enc.0.qkv.w K-padded to feat_pad
   float* d_predconv = nullptr;  // [d][3*d] im2col order
+  float* d_vocab_bias = nullptr;  // dec.out.b padded to vocab_pad
   // front-end tables
   float* d_window = nullptr; double* d_tw = nullptr; int* d_mel_off = nullptr; int* d_mel_size = nullptr;
   float* d_mel_w = nullptr; float* d_inv_ts = nullptr;
@@ -146,7 +147,7 @@ void gemm(pfhip_model* m, hipStream_t s, const float* A, int lda, const float* W
           float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
           int M, bool relu) {
   Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * Ktrue, 4.0 * ((double)M * Ktrue + (double)N * Ktrue + (double)M * N));
-  launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
+  launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, /*guard=*/false, s);
 }
 void lnorm(pfhip_model* m, hipStream_t s, const float* x, int ldx, float* y, int ldy, const std::string& name,
            int M, int D, int Dout) {
@@ -312,6 +313,10 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
       for (int ci = 0; ci < d; ++ci)
         for (int j = 0; j < 3; ++j) q[(size_t)n * 3 * d + (size_t)j * d + ci] = cw.h[((size_t)n * d + ci) * 3 + j];
     st = upload(&m->d_predconv, q);
+    if (st) return st;
+    std::vector<float> vb((size_t)m->vocab_pad, 0.f);
+    std::memcpy(vb.data(), m->W("dec.out.b").h, sizeof(float) * c.vocab);
+    st = upload(&m->d_vocab_bias, vb);
     if (st) return st;
   }
   // ---- front-end tables ------------------------------------------------------------------------------
@@ -572,7 +577,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   }
   dec_ffn("dec3.", xd, m->td.f());
   lnorm(m, s, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
-  gemm(m, s, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->W("dec.out.b").d, nullptr, 0,
+  gemm(m, s, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
        nullptr, 0, ML, false);
   HIP_TRY(hipGetLastError());
   return PFHIP_OK;
@@ -676,7 +681,7 @@ void pfhip_destroy(pfhip_model* m) {
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta})
     b->release();
-  for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_window, (void*)m->d_tw,
+  for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);

@@ -1,0 +1,112 @@
+"""ctypes binding of the operator-level C ABI (include/pfhip_ops.h) over torch CUDA tensors.
+
+torch is plumbing only here: it owns the device buffers and the stream; every op below runs the same
+hand-written gfx950 kernel that pfhip_offline_forward launches.  No fallbacks: a missing library or a
+non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import load_lib, PfhipError
+
+_vp, _ci, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = load_lib()
+    if not _bound:
+        lib.pfhip_op_gemm_f32.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
+        lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
+        lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
+        lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
+        lib.pfhip_op_cif.argtypes = [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _cf, _cf, _vp, _vp, _vp, _vp]
+        lib.pfhip_op_logsoftmax_argmax.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp]
+        _bound = True
+    return lib
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PfhipError("pfhip ops need CUDA (HIP) tensors; there is no CPU path")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise PfhipError(f"{what}: hip error {rc}")
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guard=True, out=None):
+    """C[M,N] = A[M,K] @ W[N,K]^T (+bias +R1 +R2, ReLU).  A must have ceil(M/128)*128 rows allocated
+    and W ceil(N/128)*128 rows; K % 32 == 0."""
+    K = A.shape[1]
+    M = A.shape[0] if M is None else M
+    N = W.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty((round_up(M, 128), round_up(N, 128)), dtype=torch.float32, device=A.device)
+    _ck(_lib().pfhip_op_gemm_f32(_p(A), A.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias),
+                                 _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
+                                 R2.stride(0) if R2 is not None else 0, M, N, K, 1 if relu else 0,
+                                 1 if guard else 0, _stream()), "gemm")
+    return out
+
+
+def layernorm(x, g, b, D=None, Dout=None, eps=1e-12):
+    M = x.shape[0]
+    D = x.shape[1] if D is None else D
+    Dout = D if Dout is None else Dout
+    y = torch.empty((M, Dout), dtype=torch.float32, device=x.device)
+    _ck(_lib().pfhip_op_layernorm(_p(x), x.stride(0), _p(y), y.stride(0), _p(g), _p(b), M, D, Dout, eps, _stream()), "layernorm")
+    return y
+
+
+def fsmn(v, w, off, length, res=None):
+    out = torch.zeros((v.shape[0], v.shape[1]), dtype=torch.float32, device=v.device)
+    B = off.numel()
+    _ck(_lib().pfhip_op_fsmn(_p(v), v.stride(0), _p(w), _p(res), res.stride(0) if res is not None else 0, _p(out),
+                             out.stride(0), _p(off), _p(length), B, int(length.max().item()), v.shape[1], _stream()), "fsmn")
+    return out
+
+
+def attention(Q, K, V, q_off, q_len, kv_off, kv_len, n_head, scale):
+    O = torch.zeros((Q.shape[0], n_head * 128), dtype=torch.float32, device=Q.device)
+    B = q_off.numel()
+    _ck(_lib().pfhip_op_attention(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
+                                  _p(q_off), _p(q_len), _p(kv_off), _p(kv_len), B, n_head, int(q_len.max().item()),
+                                  scale, _stream()), "attention")
+    return O
+
+
+def cif(hidden, alphas, row_off, length, threshold, tail):
+    B = row_off.numel()
+    D = hidden.shape[1]
+    stage = torch.zeros((hidden.shape[0] + B, D), dtype=torch.float32, device=hidden.device)
+    n_fires = torch.zeros(B, dtype=torch.int32, device=hidden.device)
+    token_num = torch.zeros(B, dtype=torch.int32, device=hidden.device)
+    _ck(_lib().pfhip_op_cif(_p(hidden), hidden.stride(0), _p(alphas), _p(row_off), _p(length), B, D, threshold, tail,
+                            _p(stage), _p(n_fires), _p(token_num), _stream()), "cif")
+    return stage, n_fires, token_num
+
+
+def logsoftmax_argmax(logits, V=None, want_logp=True):
+    ML = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    logp = torch.empty((ML, V), dtype=torch.float32, device=logits.device) if want_logp else None
+    ids = torch.empty(ML, dtype=torch.int32, device=logits.device)
+    _ck(_lib().pfhip_op_logsoftmax_argmax(_p(logits), logits.stride(0), ML, V, _p(logp), _p(ids), _stream()), "logsoftmax")
+    return logp, ids

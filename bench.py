@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds per wall-second of the Paraformer-large offline forward on MI355X.
+
+Workload (BASELINE.json configs[1]): batch = 32 x 30 s synthetic 16 kHz utterances per GPU, weights
+random-init with the Paraformer-large architecture (no network for the ModelScope files).  One "step"
+= one pass of the hot path (PCM resident in HBM -> fbank/LFR/CMVN -> 50-layer SAN-M encoder ->
+CIF predictor -> 16-layer decoder -> log-softmax/argmax -> token ids back on the host) over one batch.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU; utterance batches
+are sharded over ranks as independent replicas (no data-path collective), the only
+communication is the timing barrier / max-over-ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 32
+SECONDS = 30
+SR = 16000
+SEED_PCM = 20251114
+F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth_pcm(index: int, n: int, rng) -> np.ndarray:
+    """s16 = round(8000*(0.6 sin(2 pi f_i t) + 0.4 N(0,1))), f_i = 110*2^((i mod 24)/12)."""
+    t = np.arange(n, dtype=np.float64) / SR
+    f = 110.0 * 2.0 ** ((index % 24) / 12.0)
+    x = 8000.0 * (0.6 * np.sin(2 * np.pi * f * t) + 0.4 * rng.standard_normal(n))
+    return (np.clip(np.round(x), -32768, 32767) / 32768.0).astype(np.float32)
+
+
+def shard_utterance_ids(rank: int, world: int, batch: int):
+    """Weak scaling: rank r owns the global utterance indices [r*batch, (r+1)*batch) — disjoint shards,
+    independent replicas, no data-path collective."""
+    return list(range(rank * batch, (rank + 1) * batch))
+
+
+def max_over_ranks(dt: float, dist, device):
+    """The driver's contract: time = MAX over ranks of the barrier-bracketed timed region."""
+    import torch
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(man, blob, utts, seconds_per_utt):
+    """The oracle (CPU restatement, numpy/OpenBLAS fp32) timed in the reference's threading shape:
+    W worker threads sharing one model, 1 BLAS thread each, batch 1 per call
+    (onnxruntime/src/paraformer.cpp:35,470-473; websocket/run_server_offline.sh:39).  rtf formula of
+    onnxruntime/bin/funasr-onnx-offline-rtf.cpp:257-260: max thread compute time / total audio."""
+    from threadpoolctl import threadpool_limits
+    from oracle import paraformer as oracle_pf
+    W = oracle_pf.Weights(man, blob)
+    workers = len(utts)
+    busy = [0.0] * workers
+
+    def work(i):
+        t0 = time.perf_counter()
+        oracle_pf.forward_pcm(utts[i], W)
+        busy[i] = time.perf_counter() - t0
+
+    with threadpool_limits(limits=1):
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        wall = time.perf_counter() - t0
+    audio = workers * seconds_per_utt
+    return {"value": audio / max(busy), "unit": "audio-s/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} x {seconds_per_utt}-s utterances, {workers} worker threads x 1 BLAS thread, "
+                      f"batch 1 per call, numpy/OpenBLAS fp32 CPU restatement (not onnxruntime); wall {wall:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--seconds", type=int, default=SECONDS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    import importlib
+    weights = importlib.import_module("asr_2pass_amd.weights")
+
+    cfg = dict(weights.PARAFORMER_LARGE)
+    man, blob = weights.synth_weights(cfg, seed=1234)
+    model = pkg.ParaformerHip().InitAsr((man, blob), device=local_rank)
+
+    n = args.seconds * SR
+    rng = np.random.default_rng(SEED_PCM + rank)
+    utts = [synth_pcm(i, n, rng) for i in shard_utterance_ids(rank, world, args.batch)]
+    d_pcm = torch.from_numpy(np.concatenate(utts)).cuda(local_rank)
+    sample_off = np.arange(args.batch, dtype=np.int64) * n
+    n_samples = np.full(args.batch, n, np.int32)
+    stream = torch.cuda.current_stream()
+    max_tokens = n // 960 + 2
+
+    def step():
+        model.enqueue_device(d_pcm.data_ptr(), sample_off, n_samples, stream.cuda_stream)
+        return model.fetch(args.batch, max_tokens)
+
+    for _ in range(args.warmup):
+        res = step()
+    model.profile_enable(not args.no_profile)
+    model.profile_read(reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = model.profile_read(reset=True)
+    model.profile_enable(False)
+    dt = max_over_ranks(dt, dist, torch.device("cuda", local_rank))
+
+    audio_per_step = world * args.batch * args.seconds
+    value = audio_per_step * args.steps / dt
+    tokens = int(sum(len(x) for x in res["ids"]))
+
+    if rank == 0:
+        out = {
+            "metric": "audio-sec/sec (xRT) Paraformer-large offline, 30s utts",
+            "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Paraformer-large offline, batch={args.batch} x {args.seconds} s synthetic 16 kHz "
+                                   f"utterances per GPU (BASELINE.json configs[1])",
+                       "batch_per_gpu": args.batch, "utt_seconds": args.seconds, "lfr_frames_per_utt": int(res["n_frames"][0]),
+                       "tokens_per_batch": tokens, "weights": "random-init Paraformer-large (seed 1234), fp32",
+                       "parallelism": f"replicas x{world} (no collective)", "rtf": 1.0 / value},
+        }
+        if not args.no_profile:
+            g = prof["gemm"]
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches_per_step": g["launches"] / args.steps,
+                "flops_per_launch": g["flops"] / max(1, g["launches"]),
+                "per_class_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+                "per_class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)
+                                     for k, v in prof.items() if v["flops"] > 0},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            workers = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(man, blob, utts[:workers], args.seconds)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+/*
+ * pfhip_ops.h — operator-level C ABI over the same gfx950 kernels that pfhip_offline_forward launches.
+ * Device pointers in, device pointers out, asynchronous on `stream` (hipStream_t, NULL = default).
+ * Exists so that each kernel can be parity-tested and timed in isolation against the oracle; every
+ * entry names the node of the reference graph it stands for (the graph itself is the opaque
+ * `m_session_->Run`, onnxruntime/src/paraformer.cpp:541; architecture per SURVEY.md appendix A).
+ * All return 0 on success, a hipError_t value otherwise.
+ */
+#ifndef PFHIP_OPS_H_
+#define PFHIP_OPS_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MatMul/Gemm (+Add bias, +residual Adds, Relu): C[M,N] = A[M,K] W[N,K]^T ...; guard=1 bounds-checks. */
+int pfhip_op_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                      const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
+                      int guard, void* stream);
+/* LayerNormalization over the last axis. */
+int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
+                       int Dout, float eps, void* stream);
+/* FSMN memory block: depthwise Conv1d k=11 over time + identity (+residual), per utterance segment. */
+int pfhip_op_fsmn(const float* v, int ldv, const float* w, const float* res, int ldres, float* out, int ldo,
+                  const int* off, const int* len, int B, int max_len, int C, void* stream);
+/* MatMul-Softmax-MatMul of one attention block, d_k = 128. */
+int pfhip_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                       const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                       int max_q_len, float scale, void* stream);
+/* CIF integrate-and-fire (onnxruntime/src/paraformer-online.cpp:301-327) + tail slot. */
+int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
+                 float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream);
+/* LogSoftmax + ArgMax (GreedySearch/FindMax, onnxruntime/src/paraformer.cpp:386-395, util.cpp:63-74). */
+int pfhip_op_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,181 @@
+"""GPU: each hand-written kernel against the oracle (numpy fp32) through the operator-level C ABI
+(include/pfhip_ops.h).  Tolerances are stated per test; integer outputs must be exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import paraformer as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    return importlib.import_module("asr_2pass_amd.ops")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def pad_rows(a, m=128):
+    r = (a.shape[0] + m - 1) // m * m
+    out = np.zeros((r,) + a.shape[1:], a.dtype)
+    out[:a.shape[0]] = a
+    return out
+
+
+# fp32 MFMA == fmaf chain; only the summation order differs from OpenBLAS: |err| <~ 1e-6 * sqrt(K) * |terms|
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (128, 128, 32), (130, 512, 512), (500, 1536, 576),
+                                   (257, 1003, 512), (16, 512, 2048), (1000, 2048, 512)])
+@pytest.mark.parametrize("guard", [True, False])
+def test_gemm_matches_numpy(ops, M, N, K, guard):
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R1 = rng.standard_normal((M, N)).astype(np.float32)
+    R2 = rng.standard_normal((M, N)).astype(np.float32)
+    Np = (N + 127) // 128 * 128
+    dA, dW = dev(pad_rows(A)), dev(pad_rows(W))
+    dbias = dev(np.concatenate([bias, np.zeros(Np - N, np.float32)]))
+    dR1 = dev(np.pad(pad_rows(R1), ((0, 0), (0, Np - N))))
+    dR2 = dev(np.pad(pad_rows(R2), ((0, 0), (0, Np - N))))
+    for (b, r1, r2, relu) in [(None, None, None, False), (dbias, None, None, True), (dbias, dR1, None, False),
+                              (dbias, dR1, dR2, False), (None, dR1, None, True)]:
+        C = ops.gemm_f32(dA, dW, bias=b, R1=r1, R2=r2, relu=relu, M=M, N=N, guard=guard).cpu().numpy()[:M, :N]
+        ref = A @ W.T
+        if b is not None:
+            ref = ref + bias
+        if r1 is not None:
+            ref = ref + R1
+        if r2 is not None:
+            ref = ref + R2
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert np.abs(C - ref).max() < 2e-5 * max(1.0, np.sqrt(K / 512)), (M, N, K)
+
+
+def test_gemm_exact_integer_layout(ops):
+    """A = I-like with ASYMMETRIC integer W: catches any row/col swap of the MFMA C/D map bit-exactly."""
+    M, N, K = 256, 256, 64
+    A = np.zeros((M, K), np.float32)
+    for i in range(M):
+        A[i, i % K] = 1 + (i // K)
+    W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 5 + 1).astype(np.float32)
+    C = ops.gemm_f32(dev(A), dev(W)).cpu().numpy()
+    assert np.array_equal(C, A @ W.T)
+
+
+def test_gemm_in_place_residual(ops):
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((256, 512)).astype(np.float32)
+    W = (rng.standard_normal((512, 512)) / 22).astype(np.float32)
+    X = rng.standard_normal((256, 512)).astype(np.float32)
+    dX = dev(X)
+    ops.gemm_f32(dev(A), dev(W), R1=dX, out=dX, guard=False)
+    assert np.abs(dX.cpu().numpy() - (A @ W.T + X)).max() < 2e-5
+
+
+@pytest.mark.parametrize("D,Dout", [(512, 512), (560, 576), (2048, 2048)])
+def test_layernorm(ops, D, Dout):
+    rng = np.random.default_rng(D)
+    x = (rng.standard_normal((37, D)) * 3 + 1).astype(np.float32)
+    g = rng.standard_normal(D).astype(np.float32)
+    b = rng.standard_normal(D).astype(np.float32)
+    xin = np.zeros((37, Dout), np.float32)
+    xin[:, :D] = x
+    y = ops.layernorm(dev(xin), dev(g), dev(b), D=D, Dout=Dout).cpu().numpy()
+    assert np.abs(y[:, :D] - P.layer_norm(x, g, b)).max() < 1e-5
+    assert np.all(y[:, D:] == 0)
+
+
+def test_fsmn_ragged_segments(ops):
+    rng = np.random.default_rng(5)
+    lens = [1, 7, 16, 17, 40, 3]
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    M = sum(lens)
+    v = rng.standard_normal((M, 512)).astype(np.float32)
+    res = rng.standard_normal((M, 512)).astype(np.float32)
+    w = (rng.standard_normal((512, 11)) / 3).astype(np.float32)
+    for use_res in (False, True):
+        out = ops.fsmn(dev(v), dev(w), dev(off), dev(np.asarray(lens, np.int32)), res=dev(res) if use_res else None).cpu().numpy()
+        for o, L in zip(off, lens):
+            ref = P.fsmn(v[o:o + L], w) + (res[o:o + L] if use_res else 0)
+            assert np.abs(out[o:o + L] - ref).max() < 1e-5
+
+
+def _attn_case(ops, q_lens, kv_lens, seed, spike=False):
+    rng = np.random.default_rng(seed)
+    H, dk = 4, 128
+    q_off = np.concatenate([[0], np.cumsum(q_lens)[:-1]]).astype(np.int32)
+    kv_off = np.concatenate([[0], np.cumsum(kv_lens)[:-1]]).astype(np.int32)
+    Q = rng.standard_normal((sum(q_lens), H * dk)).astype(np.float32)
+    K = rng.standard_normal((sum(kv_lens), H * dk)).astype(np.float32)
+    V = rng.standard_normal((sum(kv_lens), H * dk)).astype(np.float32)
+    if spike:     # force the online-softmax rescale branch: one late key dominates one query
+        K[kv_off[0] + kv_lens[0] - 2, :dk] = Q[q_off[0] + 1, :dk] * 4
+    O = ops.attention(dev(Q), dev(K), dev(V), dev(q_off), dev(np.asarray(q_lens, np.int32)), dev(kv_off),
+                      dev(np.asarray(kv_lens, np.int32)), H, dk ** -0.5).cpu().numpy()
+    for b in range(len(q_lens)):
+        q = Q[q_off[b]:q_off[b] + q_lens[b]]
+        k = K[kv_off[b]:kv_off[b] + kv_lens[b]]
+        vv = V[kv_off[b]:kv_off[b] + kv_lens[b]]
+        ref = P.mha(q.astype(np.float64), k.astype(np.float64), vv.astype(np.float64), H)
+        got = O[q_off[b]:q_off[b] + q_lens[b]]
+        assert np.abs(got - ref).max() < 2e-5, (b, np.abs(got - ref).max())
+
+
+def test_attention_self_ragged(ops):
+    lens = [1, 31, 32, 33, 100, 129, 500]
+    _attn_case(ops, lens, lens, 11)
+
+
+def test_attention_cross_ragged(ops):
+    _attn_case(ops, [3, 120, 1, 40], [17, 500, 64, 33], 12)
+
+
+def test_attention_rescale_branch(ops):
+    _attn_case(ops, [40], [200], 13, spike=True)
+
+
+def test_cif_bit_exact_against_oracle(ops):
+    rng = np.random.default_rng(17)
+    lens = [1, 5, 83, 500, 0, 9]
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    M = sum(lens)
+    hidden = rng.standard_normal((M, 512)).astype(np.float32)
+    alphas = rng.uniform(0, 0.7, M).astype(np.float32)
+    stage, nf, tn = ops.cif(dev(hidden), dev(alphas), dev(off), dev(np.asarray(lens, np.int32)), 1.0, 0.45)
+    stage, nf, tn = stage.cpu().numpy(), nf.cpu().numpy(), tn.cpu().numpy()
+    for b, (o, L) in enumerate(zip(off, lens)):
+        if L == 0:
+            assert nf[b] == 0 and tn[b] == 0
+            continue
+        h = np.concatenate([hidden[o:o + L], np.zeros((1, 512), np.float32)])
+        a = np.concatenate([alphas[o:o + L], np.asarray([0.45], np.float32)])
+        emb, _ = P.cif(h, a, 1.0)
+        assert nf[b] == emb.shape[0]
+        assert tn[b] == int(np.floor(np.cumsum(a, dtype=np.float32)[-1]))
+        # same operations in the same order with contraction off: bit-exact
+        assert np.array_equal(stage[o + b:o + b + nf[b]], emb)
+
+
+def test_logsoftmax_argmax_first_max_wins(ops):
+    rng = np.random.default_rng(19)
+    V, Vp = 1003, 1024
+    x = rng.standard_normal((50, Vp)).astype(np.float32)
+    x[3, 700] = x[3, 20] = 9.0          # tie -> index 20 (util.cpp:63-74 strict '>')
+    x[4, :V] = -5.0                     # all equal -> index 0
+    x[5, V:] = 100.0                    # pad columns must be ignored
+    logp, ids = ops.logsoftmax_argmax(dev(x), V=V)
+    logp, ids = logp.cpu().numpy(), ids.cpu().numpy()
+    ref_ids = x[:, :V].argmax(-1)
+    assert np.array_equal(ids, ref_ids) and ids[3] == 20 and ids[4] == 0
+    z = x[:, :V] - x[:, :V].max(-1, keepdims=True)
+    ref = z - np.log(np.exp(z).sum(-1, keepdims=True))
+    assert np.abs(logp - ref).max() < 1e-5

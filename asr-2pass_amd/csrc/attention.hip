@@ -57,58 +57,72 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     for (int kb = 0; kb < 16; ++kb) qreg[kb] = *reinterpret_cast<const float4*>(qp + kb * 8);
   }
 
-  // ---- K/V tile staging --------------------------------------------------------------------------
+  // ---- K/V tile staging (named registers + sched_barriers: hipcc otherwise spills the staging
+  //      arrays to scratch and waits for the loads right where they are issued) -------------------------
   const int lrow = tid >> 5, lc4 = tid & 31;   // 8 rows x 32 float4 per pass, 4 passes
-  float4 rk[4], rv[4];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int key = kt * kKT + lrow + 8 * i;
-      if (key >= Lk) key = Lk - 1;
-      rk[i] = *reinterpret_cast<const float4*>(K + (kbase + key) * ldk + head * kHeadDim + 4 * lc4);
-      rv[i] = *reinterpret_cast<const float4*>(V + (kbase + key) * ldv + head * kHeadDim + 4 * lc4);
-    }
-  };
-  auto sstore = [&](int buf) {
-    float* ks = lds + buf * kKVBuf;
-    float* vs = ks + kKT * kKS;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(ks + (lrow + 8 * i) * kKS + 4 * lc4) = rk[i];
-      *reinterpret_cast<float4*>(vs + (lrow + 8 * i) * kHeadDim + 4 * lc4) = rv[i];
-    }
-  };
+  float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+  const float* Kh = K + kbase * ldk + head * kHeadDim + 4 * lc4;
+  const float* Vh = V + kbase * ldv + head * kHeadDim + 4 * lc4;
+#define PFHIP_KV_LOAD1(RK, RV, i, kt)                                                   \
+  do {                                                                                  \
+    int key_ = (kt) * kKT + lrow + 8 * (i);                                             \
+    key_ = key_ < Lk ? key_ : Lk - 1;                                                   \
+    RK = *reinterpret_cast<const float4*>(Kh + (size_t)key_ * ldk);                     \
+    RV = *reinterpret_cast<const float4*>(Vh + (size_t)key_ * ldv);                     \
+  } while (0)
+#define PFHIP_KV_LOAD(kt)                                                               \
+  do {                                                                                  \
+    PFHIP_KV_LOAD1(rk0, rv0, 0, kt); PFHIP_KV_LOAD1(rk1, rv1, 1, kt);                   \
+    PFHIP_KV_LOAD1(rk2, rv2, 2, kt); PFHIP_KV_LOAD1(rk3, rv3, 3, kt);                   \
+  } while (0)
+#define PFHIP_KV_STORE(buf)                                                             \
+  do {                                                                                  \
+    float* ks_ = lds + (buf) * kKVBuf + lrow * kKS + 4 * lc4;                           \
+    float* vs_ = lds + (buf) * kKVBuf + kKT * kKS + lrow * kHeadDim + 4 * lc4;          \
+    *reinterpret_cast<float4*>(ks_) = rk0;                                              \
+    *reinterpret_cast<float4*>(ks_ + 8 * kKS) = rk1;                                    \
+    *reinterpret_cast<float4*>(ks_ + 16 * kKS) = rk2;                                   \
+    *reinterpret_cast<float4*>(ks_ + 24 * kKS) = rk3;                                   \
+    *reinterpret_cast<float4*>(vs_) = rv0;                                              \
+    *reinterpret_cast<float4*>(vs_ + 8 * kHeadDim) = rv1;                               \
+    *reinterpret_cast<float4*>(vs_ + 16 * kHeadDim) = rv2;                              \
+    *reinterpret_cast<float4*>(vs_ + 24 * kHeadDim) = rv3;                              \
+  } while (0)
 
-  f32x16 oacc[4];
+  f32x16 oacc0, oacc1, oacc2, oacc3;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  for (int e = 0; e < 16; ++e) { oacc0[e] = 0.f; oacc1[e] = 0.f; oacc2[e] = 0.f; oacc3[e] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
   const int nkt = (Lk + kKT - 1) / kKT;
-  gload(0);
-  sstore(0);
+  PFHIP_KV_LOAD(0);
+  PFHIP_KV_STORE(0);
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nkt) gload(kt + 1);
+    // unconditional prefetch of the next tile (the last iteration re-fetches its own): straight-line body
+    PFHIP_KV_LOAD(kt + 1 < nkt ? kt + 1 : kt);
+    __builtin_amdgcn_sched_barrier(0);
     const float* ks = lds + cur * kKVBuf;
     const float* vs = ks + kKT * kKS;
 
-    // S^T[key][q] = sum_d K[key][d] * Q[q][d]
+    // S^T[key][q] = sum_d K[key][d] * Q[q][d]; the K fragment of k-block kb+1 is read under the 4 MFMAs of kb
     f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
     const float* kp = ks + r * kKS + 4 * h;
+    float4 ka = *reinterpret_cast<const float4*>(kp);
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
-      const float4 a = *reinterpret_cast<const float4*>(kp + kb * 8);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[kb].x, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[kb].y, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[kb].z, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[kb].w, sacc, 0, 0, 0);
+      const float4 kn = *reinterpret_cast<const float4*>(kp + (kb < 15 ? kb + 1 : kb) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qreg[kb].x, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qreg[kb].y, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qreg[kb].z, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qreg[kb].w, sacc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ka = kn;
     }
 
     // online softmax for query column r; this lane holds keys (e&3) + 8*(e>>2) + 4*h of the tile
@@ -136,42 +150,47 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     m_run = m_new;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+      for (int e = 0; e < 16; ++e) { oacc0[e] *= alpha; oacc1[e] *= alpha; oacc2[e] *= alpha; oacc3[e] *= alpha; }
     }
 
-    // O^T[d][q] += sum_key V[key][d] * P^T[key][q]
+    // O^T[d][q] += sum_key V[key][d] * P^T[key][q]; V values of step e+1 are read under the 4 MFMAs of e
     const float* vp = vs + (4 * h) * kHeadDim + r;
+    float va0 = vp[0], va1 = vp[32], va2 = vp[64], va3 = vp[96];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float* vrow = vp + ((e & 3) + 8 * (e >> 2)) * kHeadDim;
+      const int en = e < 15 ? e + 1 : e;
+      const float* vrow = vp + ((en & 3) + 8 * (en >> 2)) * kHeadDim;
+      const float vn0 = vrow[0], vn1 = vrow[32], vn2 = vrow[64], vn3 = vrow[96];
+      __builtin_amdgcn_sched_barrier(0);
       const float pb = sacc[e];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], pb, oacc[dt], 0, 0, 0);
+      oacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, pb, oacc0, 0, 0, 0);
+      oacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, pb, oacc1, 0, 0, 0);
+      oacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(va2, pb, oacc2, 0, 0, 0);
+      oacc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(va3, pb, oacc3, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      va0 = vn0; va1 = vn1; va2 = vn2; va3 = vn3;
     }
 
-    if (kt + 1 < nkt) sstore(cur ^ 1);
+    PFHIP_KV_STORE(cur ^ 1);
     __syncthreads();
   }
+#undef PFHIP_KV_LOAD1
+#undef PFHIP_KV_LOAD
+#undef PFHIP_KV_STORE
 
   // ---- normalise, transpose through LDS, store full rows ------------------------------------------
   const float inv_l = 1.0f / l_run;
   float* os = lds + wave * (kQW * kKS);
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 o4;
-      o4.x = oacc[dt][4 * g + 0] * inv_l;
-      o4.y = oacc[dt][4 * g + 1] * inv_l;
-      o4.z = oacc[dt][4 * g + 2] * inv_l;
-      o4.w = oacc[dt][4 * g + 3] * inv_l;
-      // registers 4g..4g+3 are d = dt*32 + 8g + 4h + (0..3) of query column r
-      *reinterpret_cast<float4*>(os + r * kKS + dt * 32 + 8 * g + 4 * h) = o4;
-    }
+#define PFHIP_O_STORE(OACC, dt)                                                          \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
+    float4 o4;                                                                           \
+    o4.x = OACC[4 * g + 0] * inv_l; o4.y = OACC[4 * g + 1] * inv_l;                      \
+    o4.z = OACC[4 * g + 2] * inv_l; o4.w = OACC[4 * g + 3] * inv_l;                      \
+    /* registers 4g..4g+3 are d = dt*32 + 8g + 4h + (0..3) of query column r */          \
+    *reinterpret_cast<float4*>(os + r * kKS + (dt) * 32 + 8 * g + 4 * h) = o4;           \
   }
+  PFHIP_O_STORE(oacc0, 0) PFHIP_O_STORE(oacc1, 1) PFHIP_O_STORE(oacc2, 2) PFHIP_O_STORE(oacc3, 3)
+#undef PFHIP_O_STORE
   __syncthreads();
   // each wave stores its own 32 x 128 tile: 2 rows per pass (32 lanes x float4 = one 512-B row)
 #pragma unroll

@@ -12,6 +12,11 @@
 // buffers, next tile's global loads in flight under the current tile's 64 MFMAs per wave.
 // A lane reads 4 consecutive k of its row with one ds_read_b128; lane half h takes k = 8*kb+4*h+kk
 // at MFMA step kk, for A and B alike, so the k permutation cancels.
+//
+// Epilogue: the 32x32 accumulator layout has ONE column per lane, so storing from registers means 64
+// four-byte stores (and 64+64 four-byte residual loads) per lane — store-issue-bound, measured at
+// ~25 % of the kernel.  The tile is instead transposed through the (now idle) LDS and written as
+// full 512-byte rows with 16-byte accesses; bias / residual / ReLU are applied on the row pass.
 #include "kernels.h"
 
 namespace pfhip {
@@ -19,14 +24,20 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kLds = 36;  // padded row stride in floats
+constexpr int kLds = 36;                       // padded operand row stride (floats)
+constexpr int kStage = kTileM * kLds;          // floats per operand per buffer
+constexpr int kCs = kTileN + 4;                // padded C-tile row stride (floats)
+constexpr int kLdsFloats = 4 * kStage;         // 73,728 B: A0 A1 B0 B1; the C tile (128 x 132) reuses it
+static_assert(kTileM * kCs <= kLdsFloats, "C tile must fit the operand buffers");
 
 template <bool GUARD, bool HAS_BIAS, bool HAS_R1, bool HAS_R2, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
-    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C,
-    int ldc, const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) float As[2][kTileM * kLds];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kTileN * kLds];
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
+    const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N,
+    int K, int tiles_n, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* const As = lds;                  // [2][128][36]
+  float* const Bs = lds + 2 * kStage;     // [2][128][36]
 
   // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): blocks that share an XCD
   // (equal blockIdx % 8) walk a contiguous run of tiles, n fastest, so an A row-panel is fetched into
@@ -62,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   } while (0)
 #define PFHIP_SSTORE(buf)                                                             \
   do {                                                                                \
-    float* as_ = &As[buf][lrow * kLds + 4 * lc4];                                     \
-    float* bs_ = &Bs[buf][lrow * kLds + 4 * lc4];                                     \
+    float* as_ = As + (buf) * kStage + lrow * kLds + 4 * lc4;                         \
+    float* bs_ = Bs + (buf) * kStage + lrow * kLds + 4 * lc4;                         \
     *reinterpret_cast<float4*>(as_) = ra0;                                            \
     *reinterpret_cast<float4*>(as_ + 32 * kLds) = ra1;                                \
     *reinterpret_cast<float4*>(as_ + 64 * kLds) = ra2;                                \
@@ -86,78 +97,123 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   const int a_off = (wr * 64 + r) * kLds + 4 * h;
   const int b_off = (wc * 64 + r) * kLds + 4 * h;
 
+  // Software pipeline (one barrier per K-tile, never an empty matrix pipe around it):
+  //   top      : global loads of tile kt+1 go out (in flight under 48 MFMAs)
+  //   kb 0..2  : ds_read fragments of k-block kb+1 | 16 MFMAs of k-block kb
+  //              (before the MFMAs of k-block 2: ds_write tile kt+1 into the other buffer)
+  //   then     : barrier -> ds_read k-block 0 of tile kt+1 | 16 MFMAs of k-block 3
+  float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
+#define PFHIP_FRAG_LOAD(A0, A1, B0, B1, buf, kb)                                              \
+  do {                                                                                        \
+    const float* as_ = As + (buf) * kStage + a_off + (kb) * 8;                                \
+    const float* bs_ = Bs + (buf) * kStage + b_off + (kb) * 8;                                \
+    A0 = *reinterpret_cast<const float4*>(as_);                                               \
+    A1 = *reinterpret_cast<const float4*>(as_ + 32 * kLds);                                   \
+    B0 = *reinterpret_cast<const float4*>(bs_);                                               \
+    B1 = *reinterpret_cast<const float4*>(bs_ + 32 * kLds);                                   \
+  } while (0)
+#define PFHIP_MFMA4(A0, A1, B0, B1, c)                                                \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc00, 0, 0, 0);           \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B1.c, acc01, 0, 0, 0);           \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc10, 0, 0, 0);           \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc11, 0, 0, 0);
+#define PFHIP_MFMA16(A0, A1, B0, B1) \
+  PFHIP_MFMA4(A0, A1, B0, B1, x) PFHIP_MFMA4(A0, A1, B0, B1, y) PFHIP_MFMA4(A0, A1, B0, B1, z) PFHIP_MFMA4(A0, A1, B0, B1, w)
+
+  PFHIP_FRAG_LOAD(fa0, fa1, fb0, fb1, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    // unconditional (the last iteration re-fetches its own tile): keeps the loop body straight-line so
-    // the loads stay in flight under the MFMAs instead of being waited for at once
+    // unconditional (the last iteration re-fetches its own tile): keeps the loop body straight-line
     const int knext = (kt + 1 < nk ? kt + 1 : kt) * kTileK;
     PFHIP_GLOAD(knext);
     __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the loads to just above their ds_write
-    const float* as = &As[cur][a_off];
-    const float* bs = &Bs[cur][b_off];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const float4 a0 = *reinterpret_cast<const float4*>(as + kb * 8);
-      const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * kLds + kb * 8);
-      const float4 b0 = *reinterpret_cast<const float4*>(bs + kb * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(bs + 32 * kLds + kb * 8);
-#define PFHIP_MFMA4(c)                                                              \
-  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc00, 0, 0, 0);         \
-  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc01, 0, 0, 0);         \
-  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc10, 0, 0, 0);         \
-  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc11, 0, 0, 0);
-      PFHIP_MFMA4(x) PFHIP_MFMA4(y) PFHIP_MFMA4(z) PFHIP_MFMA4(w)
-#undef PFHIP_MFMA4
-    }
+    PFHIP_FRAG_LOAD(ga0, ga1, gb0, gb1, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);   // fragment reads first, then the MFMAs that hide their latency
+    PFHIP_MFMA16(fa0, fa1, fb0, fb1)
     __builtin_amdgcn_sched_barrier(0);
-    PFHIP_SSTORE(cur ^ 1);
+    PFHIP_FRAG_LOAD(fa0, fa1, fb0, fb1, cur, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    PFHIP_MFMA16(ga0, ga1, gb0, gb1)
+    __builtin_amdgcn_sched_barrier(0);
+    PFHIP_FRAG_LOAD(ga0, ga1, gb0, gb1, cur, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    PFHIP_SSTORE(cur ^ 1);               // the other buffer: its ds_writes drain under the next 16 MFMAs
+    __builtin_amdgcn_sched_barrier(0);   // (measured +4 % over writing right in front of the barrier)
+    PFHIP_MFMA16(fa0, fa1, fb0, fb1)
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    PFHIP_FRAG_LOAD(fa0, fa1, fb0, fb1, cur ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    PFHIP_MFMA16(ga0, ga1, gb0, gb1)
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef PFHIP_FRAG_LOAD
+#undef PFHIP_MFMA4
+#undef PFHIP_MFMA16
 #undef PFHIP_GLOAD
 #undef PFHIP_SSTORE
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  // Unguarded form: C / R1 / R2 have ceil(M/128)*128 rows and ceil(N/128)*128 columns allocated and
-  // bias is readable up to the padded N (pad outputs are junk nobody reads) -> no per-element branches.
+  // ---- epilogue: accumulators -> LDS (C/D map: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)) ----
+  __syncthreads();                        // every wave has finished reading operand fragments
+  float* const Cs = lds;
+  {
+    float* cw = Cs + (wr * 64 + 4 * h) * kCs + wc * 64 + r;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + r;
-      const bool col_ok = !GUARD || col < N;
-      float bv = 0.f;
-      if (HAS_BIAS && col_ok) bv = bias[col];
-      const int rbase = m0 + wr * 64 + i * 32 + 4 * h;
-      const f32x16& accv = (i == 0) ? (j == 0 ? acc00 : acc01) : (j == 0 ? acc10 : acc11);
-      float r1v[16], r2v[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        const bool ok = !GUARD || (col_ok && row < M);
-        const int rr = (GUARD && !ok) ? 0 : row;
-        const int cc = (GUARD && !ok) ? 0 : col;
-        r1v[e] = HAS_R1 ? R1[(size_t)rr * ldr1 + cc] : 0.f;
-        r2v[e] = HAS_R2 ? R2[(size_t)rr * ldr2 + cc] : 0.f;
+    for (int e = 0; e < 16; ++e) {
+      const int ro = ((e & 3) + 8 * (e >> 2)) * kCs;
+      cw[ro] = acc00[e];
+      cw[ro + 32] = acc01[e];
+      cw[ro + 32 * kCs] = acc10[e];
+      cw[ro + 32 * kCs + 32] = acc11[e];
+    }
+  }
+  __syncthreads();
+  // ---- row pass: 8 rows x 512 B per step, 16-byte accesses ---------------------------------------
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (HAS_BIAS) {
+    if (!GUARD || gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    else {
+      if (gcol < N) bv.x = bias[gcol];
+      if (gcol + 1 < N) bv.y = bias[gcol + 1];
+      if (gcol + 2 < N) bv.z = bias[gcol + 2];
+    }
+  }
+#pragma unroll 4
+  for (int pass = 0; pass < 16; ++pass) {
+    const int row = pass * 8 + rsub;
+    const int grow = m0 + row;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (!GUARD || (grow < M && gcol + 3 < N)) {
+      if (HAS_R1) {
+        const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        float v = accv[e] + bv;
-        if (HAS_R1) v += r1v[e];
-        if (HAS_R2) v += r2v[e];
-        if (RELU) v = fmaxf(v, 0.f);
-        if (!GUARD || (col_ok && row < M)) C[(size_t)row * ldc + col] = v;
+      if (HAS_R2) {
+        const float4 t = *reinterpret_cast<const float4*>(R2 + (size_t)grow * ldr2 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+    } else if (grow < M && gcol < N) {      // ragged right edge (GUARD only): element-wise
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int q = 0; q < 4 && gcol + q < N; ++q) {
+        float o = vv[q];
+        if (HAS_R1) o += R1[(size_t)grow * ldr1 + gcol + q];
+        if (HAS_R2) o += R2[(size_t)grow * ldr2 + gcol + q];
+        if (RELU) o = fmaxf(o, 0.f);
+        C[(size_t)grow * ldc + gcol + q] = o;
       }
     }
   }
 }
 
-}  // namespace
-
 template <bool GUARD>
-static void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
-                           const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
-                           int M, int N, int K, bool relu, hipStream_t s) {
+void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                    const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu,
+                    hipStream_t s) {
   const int tiles_m = (M + kTileM - 1) / kTileM;
   const int tiles_n = (N + kTileN - 1) / kTileN;
   const int n_tiles = tiles_m * tiles_n;
@@ -186,6 +242,8 @@ static void launch_variant(const float* A, int lda, const float* W, int ldw, flo
   }
 #undef PFHIP_GEMM
 }
+
+}  // namespace
 
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, int M,

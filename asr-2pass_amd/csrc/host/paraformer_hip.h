@@ -1,0 +1,85 @@
+// Host side above the C ABI, in the reference's own language (C++): `ParaformerHip`, the sibling of
+// `funasr::Paraformer` / `funasr::ParaformerTorch` behind the plug-in seam `class funasr::Model`
+// (onnxruntime/include/model.h:13-46).  Same method names, argument meaning and error behaviour as the
+// reference classes (onnxruntime/src/paraformer.cpp:21-53,463-589; paraformer-torch.cpp:301-475).
+//
+// Built stand-alone here (against the small interface below, which repeats the virtuals of model.h
+// that this path uses, because model.h drags in openfst/yaml-cpp/glog headers that are out of scope);
+// inside the reference tree define PFHIP_WITH_FUNASR to derive from the real funasr::Model instead
+// (INTEGRATION.md shows the CMake switch and the two-line factory change).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/pfhip.h"
+
+#ifdef PFHIP_WITH_FUNASR
+#include "model.h"
+#include "vocab.h"
+namespace funasr {
+using ParaformerHipBase = Model;
+}
+#else
+namespace funasr {
+// The subset of `class Model` (model.h:13-46) on the offline Paraformer path, signature for signature.
+class ParaformerHipBase {
+ public:
+  virtual ~ParaformerHipBase() {}
+  virtual void StartUtterance() = 0;
+  virtual void EndUtterance() = 0;
+  virtual void Reset() = 0;
+  virtual void InitAsr(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
+                       const std::string& token_file, int thread_num) = 0;
+  virtual std::vector<std::string> Forward(float** din, int* len, bool input_finished,
+                                           const std::vector<std::vector<float>>& hw_emb, void* wfst_decoder,
+                                           int batch_in) = 0;
+  virtual std::vector<std::vector<float>> CompileHotwordEmbedding(std::string& hotwords) = 0;
+  virtual std::string Rescoring() = 0;
+  virtual int GetAsrSampleRate() = 0;
+  virtual void SetBatchSize(int batch_size) = 0;
+  virtual int GetBatchSize() = 0;
+};
+}  // namespace funasr
+#endif
+
+namespace funasr {
+
+class ParaformerHip : public ParaformerHipBase {
+ public:
+  ParaformerHip();
+  ~ParaformerHip() override;
+
+  // am_model = weight blob (<dir>/model.pfhip.bin), am_config = its JSON manifest; am_cmvn is folded
+  // into the container (cmvn.* tensors); token_file = tokens.json (a JSON array of strings).
+  void InitAsr(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
+               const std::string& token_file, int thread_num) override;
+  // Returns batch_in strings.  "" for an utterance without one full fbank window (paraformer.cpp:477-480)
+  // and for every item when the device call fails (the reference logs and returns "" too, :582-588).
+  std::vector<std::string> Forward(float** din, int* len, bool input_finished,
+                                   const std::vector<std::vector<float>>& hw_emb, void* wfst_decoder,
+                                   int batch_in) override;
+  // Plain model: one zero row of encoder_size, as Paraformer::CompileHotwordEmbedding does when
+  // use_hotword is false (paraformer.cpp:594-599).
+  std::vector<std::vector<float>> CompileHotwordEmbedding(std::string& hotwords) override;
+  void StartUtterance() override {}
+  void EndUtterance() override {}
+  void Reset() override {}
+  std::string Rescoring() override { return ""; }
+  int GetAsrSampleRate() override;
+  void SetBatchSize(int batch_size) override { batch_size_ = batch_size; }
+  int GetBatchSize() override { return batch_size_; }
+
+  // token ids of the last Forward, per utterance (what GreedySearch computed, paraformer.cpp:386-395)
+  const std::vector<std::vector<int>>& LastTokenIds() const { return last_ids_; }
+  void SetDevice(int device) { device_ = device; }
+
+ private:
+  std::string IdsToString(const std::vector<int>& ids) const;
+  pfhip_model* handle_ = nullptr;
+  int device_ = 0;
+  int batch_size_ = 1;
+  std::vector<std::string> tokens_;
+  std::vector<std::vector<int>> last_ids_;
+};
+
+}  // namespace funasr

@@ -27,6 +27,8 @@ ABI_SYMBOLS = [
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
+    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
+    "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
 ]
 
 
@@ -78,6 +80,13 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_offline_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
     lib.pfhip_extract_feats.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ctypes.c_size_t, vp]
     lib.pfhip_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.pfhip_stream_create.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(vp)]
+    lib.pfhip_stream_destroy.argtypes = [vp]
+    lib.pfhip_stream_destroy.restype = None
+    lib.pfhip_stream_reset.argtypes = [vp]
+    lib.pfhip_stream_forward.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.pfhip_stream_set_debug.argtypes = [vp, ci]
+    lib.pfhip_stream_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -268,3 +277,48 @@ class ParaformerHip:
         _check(self._lib, self._lib.pfhip_profile_read(self._h, ctypes.byref(p), 1 if reset else 0))
         return {KCLASS_NAMES[i]: dict(ms=p.ms[i], launches=p.launches[i], flops=p.flops[i], bytes=p.bytes[i])
                 for i in range(PFHIP_NUM_KCLASS)}
+
+
+class ParaformerOnlineHip:
+    """Host-side mirror of `funasr::ParaformerOnline` (onnxruntime/src/paraformer-online.cpp): one object per
+    connection, built from the (online) model handle like `ParaformerOnline(Model* offline_handle, chunk_size)`
+    (:12-62).  Forward(din, len, input_finished) keeps the reference's name and meaning (:525-601) and returns
+    the token ids emitted by the call (the reference returns their text)."""
+
+    def __init__(self, offline_handle: ParaformerHip, chunk_size=(5, 10, 5)):
+        self._lib = load_lib()
+        self._model = offline_handle          # keeps the model alive
+        self._h = ctypes.c_void_p()
+        cs = (ctypes.c_int * 3)(*chunk_size)
+        _check(self._lib, self._lib.pfhip_stream_create(offline_handle.handle, cs, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.pfhip_stream_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Reset(self):
+        _check(self._lib, self._lib.pfhip_stream_reset(self._h))
+
+    def set_debug(self, on=True):
+        _check(self._lib, self._lib.pfhip_stream_set_debug(self._h, 1 if on else 0))
+
+    def Forward(self, din, len_=None, input_finished=False):
+        x = np.ascontiguousarray(din if len_ is None else np.asarray(din)[:len_], dtype=np.float32)
+        ids = np.zeros(256, np.int32)
+        n = ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_stream_forward(self._h, x.ctypes.data if x.size else None, int(x.size),
+                                                         1 if input_finished else 0, ids.ctypes.data, 256, ctypes.byref(n)))
+        return [int(v) for v in ids[:n.value]]
+
+    def get_tensor(self, name: str, cap_floats: int) -> np.ndarray:
+        buf = np.zeros(max(cap_floats, 1), np.float32)
+        n = ctypes.c_size_t(0)
+        _check(self._lib, self._lib.pfhip_stream_get_tensor(self._h, name.encode(), buf.ctypes.data, cap_floats, ctypes.byref(n)))
+        return buf[:n.value]

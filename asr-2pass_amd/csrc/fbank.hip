@@ -29,7 +29,8 @@ struct FbankParams {
   int B;
   int total_frames;
   FbankTables tb;
-  float* feats;
+  float* feats;     // LFR+CMVN output [M,560] (offline), or null
+  float* fb_out;    // raw log-mel frames [total_frames,80] (streaming: ParaformerOnline::FbankKaldi), or null
 };
 
 constexpr int kFrameLen = 400, kFrameShift = 160, kNfft = 512, kMels = 80, kLfrM = 7, kLfrN = 6;
@@ -158,6 +159,14 @@ __global__ __launch_bounds__(256) void fbank_lfr_cmvn_kernel(FbankParams p) {
     melv[u] = val;
   }
   if (!active) return;
+  if (p.fb_out) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bin = lane + 64 * u;
+      if (bin < kMels) p.fb_out[(size_t)g * kMels + bin] = melv[u];
+    }
+    return;
+  }
 
   // ---- LFR gather + CMVN -----------------------------------------------------------------------
   const int T = (F + kLfrN - 1) / kLfrN;
@@ -191,9 +200,16 @@ void launch_fbank_lfr_cmvn(const float* pcm, const int64_t* sample_off, const in
                            const int* nframes, const int* row_off, int B, int total_frames,
                            FbankTables tb, float* feats, hipStream_t s) {
   if (total_frames <= 0) return;
-  FbankParams p{pcm, sample_off, frame_off, nframes, row_off, B, total_frames, tb, feats};
+  FbankParams p{pcm, sample_off, frame_off, nframes, row_off, B, total_frames, tb, feats, nullptr};
   const int blocks = (total_frames + 3) / 4;
   hipLaunchKernelGGL(fbank_lfr_cmvn_kernel, dim3(blocks), dim3(256), 0, s, p);
+}
+
+void launch_fbank_frames(const float* pcm, const int64_t* sample_off, const int* frame_off, const int* nframes,
+                         int total_frames, FbankTables tb, float* fb_out, hipStream_t s) {
+  if (total_frames <= 0) return;
+  FbankParams p{pcm, sample_off, frame_off, nframes, nullptr, 1, total_frames, tb, nullptr, fb_out};
+  hipLaunchKernelGGL(fbank_lfr_cmvn_kernel, dim3((total_frames + 3) / 4), dim3(256), 0, s, p);
 }
 
 // ---- embed: x*sqrt(d_model) + sinusoidal PE (paraformer-online.cpp:549-555, 240-268) ----------

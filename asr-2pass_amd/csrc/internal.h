@@ -1,0 +1,154 @@
+// Internal definitions shared by pfhip.cpp (offline forward) and stream.cpp (chunk-streaming forward).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pfhip.h"
+#include "kernels.h"
+
+namespace pfhip_detail {
+
+std::string& last_error();          // thread-local, defined in pfhip.cpp
+
+inline pfhip_status fail(pfhip_status st, const std::string& msg) {
+  last_error() = msg;
+  return st;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return pfhip_detail::fail(PFHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    bytes = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  float* f() const { return static_cast<float*>(p); }
+  int* i() const { return static_cast<int*>(p); }
+};
+
+struct Tensor {
+  const float* d = nullptr;   // device
+  const float* h = nullptr;   // host (only valid during create)
+  std::vector<int> shape;
+  size_t n = 0;
+};
+
+struct Config {
+  int d_model = 512, n_head = 4, ffn = 2048, enc_layers = 50, dec_layers = 16, dec_ffn = 2048;
+  int kernel = 11, vocab = 8404, n_mels = 80, lfr_m = 7, lfr_n = 6, pred_residual = 0;
+  float cif_threshold = 1.0f, tail_threshold = 0.45f, smooth_factor = 1.0f, noise_threshold = 0.0f;
+  int sample_rate = 16000;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct ProfRec { int cls; hipEvent_t e0, e1; };
+
+}  // namespace pfhip_detail
+
+using pfhip_detail::Buf;
+using pfhip_detail::Config;
+using pfhip_detail::ProfRec;
+using pfhip_detail::Tensor;
+
+struct pfhip_model {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  std::mutex mu;
+  Config cfg;
+  int feat_dim = 560, feat_pad = 576, vocab_pad = 8448;
+
+  float* d_blob = nullptr;
+  std::map<std::string, Tensor> t;
+  float* d_w0qkv = nullptr;     // enc.0.qkv.w K-padded to feat_pad
+  float* d_predconv = nullptr;  // [d][3*d] im2col order
+  float* d_vocab_bias = nullptr;  // dec.out.b padded to vocab_pad
+  // front-end tables
+  float* d_window = nullptr; double* d_tw = nullptr; int* d_mel_off = nullptr; int* d_mel_size = nullptr;
+  float* d_mel_w = nullptr; float* d_inv_ts = nullptr;
+
+  // workspace
+  Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
+  Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta;
+  void* h_meta = nullptr; size_t h_meta_cap = 0;     // pinned
+  int* h_counts = nullptr;                            // pinned [2*B]
+  size_t h_counts_cap = 0;
+
+  // state of the last forward
+  int B = 0, M = 0, ML = 0, maxT = 0, maxL = 0;
+  std::vector<int> T, row_off, n_fires, token_num, tok_off;
+  bool have_logp = false;
+  // device views into meta / dmeta
+  int *m_frame_off = nullptr, *m_nframes = nullptr, *m_row_off = nullptr, *m_len = nullptr,
+      *m_row_pos = nullptr, *m_row_len = nullptr;
+  int64_t* m_sample_off = nullptr;
+  int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  pfhip_profile prof{};
+  hipStream_t prof_stream = nullptr;
+
+  const Tensor& W(const std::string& n) const { return t.at(n); }
+};
+
+namespace pfhip_detail {
+
+using pfhip::launch_gemm_f32;
+
+struct Scope {
+  pfhip_model* m; hipStream_t s; int cls; hipEvent_t e1 = nullptr;
+  Scope(pfhip_model* m_, hipStream_t s_, int cls_, double flops, double bytes) : m(m_), s(s_), cls(cls_) {
+    if (!m->prof_on) return;
+    if (m->ev_used + 2 > m->ev_pool.size()) {
+      for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; m->ev_pool.push_back(e); }
+    }
+    hipEvent_t e0 = m->ev_pool[m->ev_used++];
+    e1 = m->ev_pool[m->ev_used++];
+    (void)hipEventRecord(e0, s);
+    m->prof_recs.push_back({cls, e0, e1});
+    m->prof.flops[cls] += flops;
+    m->prof.bytes[cls] += bytes;
+    m->prof.launches[cls] += 1;
+  }
+  ~Scope() { if (e1) (void)hipEventRecord(e1, s); }
+};
+
+enum { K_GEMM = 0, K_ATTN = 1, K_LN = 2, K_FSMN = 3, K_FBANK = 4, K_CIF = 5, K_HEAD = 6, K_OTHER = 7 };
+
+inline void gemm(pfhip_model* m, hipStream_t s, const float* A, int lda, const float* Wd, int N, int K, int Ktrue,
+          float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+          int M, bool relu) {
+  Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * Ktrue, 4.0 * ((double)M * Ktrue + (double)N * Ktrue + (double)M * N));
+  launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, /*guard=*/false, s);
+}
+inline void lnorm(pfhip_model* m, hipStream_t s, const float* x, int ldx, float* y, int ldy, const std::string& name,
+           int M, int D, int Dout) {
+  Scope sc(m, s, K_LN, 8.0 * M * D, 8.0 * M * D);
+  pfhip::launch_layernorm(x, ldx, y, ldy, m->W(name + ".g").d, m->W(name + ".b").d, M, D, Dout, 1e-12f, s);
+}
+
+
+}  // namespace pfhip_detail

@@ -28,6 +28,11 @@ void launch_fbank_lfr_cmvn(const float* pcm, const int64_t* sample_off, const in
                            const int* nframes, const int* row_off, int B, int total_frames,
                            FbankTables tb, float* feats, hipStream_t s);
 
+// Streaming form (ParaformerOnline::FbankKaldi, paraformer-online.cpp:119-145): one utterance, raw
+// log-mel frames [total_frames, 80] out, no LFR/CMVN.  sample_off/frame_off/nframes: 1/2/1 entries.
+void launch_fbank_frames(const float* pcm, const int64_t* sample_off, const int* frame_off, const int* nframes,
+                         int total_frames, FbankTables tb, float* fb_out, hipStream_t s);
+
 // x0[row][0..D) = feats*scale + PE(row_pos[row]+1); columns D..ldx are zeroed.
 void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_pos, int M,
                   const float* inv_timescale, float scale, hipStream_t s);
@@ -80,5 +85,23 @@ void launch_compact(const float* stage, float* emb, const int* tok_row_src, int 
 // per row: log-softmax over V logits, argmax (first max wins, util.cpp:63-74).  logp may be null.
 void launch_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids,
                               hipStream_t s);
+
+// ---- chunk-streaming pieces ----------------------------------------------
+// OnlineLfrCmvn + x*sqrt(d) + GetPosEmb (paraformer-online.cpp:196-238, 549-555, 240-268) for `n_rows`
+// LFR rows: row i = frames [6i, 6i+7) of fb (T frames incl. the splice cache), the tail replicated with
+// the last frame; out[i] = ((x + mean) * istd) * scale + PE(pos0 + i + 1).  out has row stride ldo.
+void launch_stream_lfr(const float* fb, int T, int n_rows, const float* mean, const float* istd, float scale,
+                       const float* inv_ts, int pos0, float* out, int ldo, hipStream_t s);
+// dst[r][0..ncols) = src[r][0..ncols) (or 0 when src == nullptr), columns ncols..ldd zeroed.
+void launch_rows_copy(float* dst, int ldd, const float* src, int lds_, int nrows, int ncols, hipStream_t s);
+// CifSearch (paraformer-online.cpp:270-345): carry (hidden,alpha) prepended, alphas[0:pre) and [suf:)
+// zeroed, optional tail; fired frames -> emb rows, *n_fire; carry updated in place.
+void launch_cif_stream(const float* enc, int lde, const float* alphas, int n, int pre, int suf, int is_last,
+                       float threshold, float tail, float* carry_hidden, float* carry_alpha, float* emb,
+                       int* n_fire, int D, hipStream_t s);
+// Causal FSMN with a (k-1)-row left cache: out[n] = res[n] + t2[n] + sum_j w[c][j]*xcat[n+j], xcat =
+// [cache; t2]; cache <- last k-1 rows of xcat.  N rows, C channels (C % 4 == 0), k == 11.
+void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, float* cache, int N,
+                        int C, hipStream_t s);
 
 }  // namespace pfhip

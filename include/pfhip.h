@@ -98,6 +98,31 @@ pfhip_status pfhip_extract_feats(pfhip_model* m, const float* const* pcm, const 
                                  int batch, float* feats_out, size_t feats_cap_floats,
                                  int32_t* n_frames_out);
 
+/* ---- chunk-streaming forward ---------------------------------------------------------------------
+ * One pfhip_stream per connection = one `funasr::ParaformerOnline` (onnxruntime/src/paraformer-online.cpp),
+ * created from the ONLINE model's container; its caches (fbank splice cache, [5|10|5] overlap window,
+ * CIF carry, 16 decoder FSMN caches) live in HBM.  Calls on streams of one model are serialised.
+ *   pfhip_stream_create   <-> ParaformerOnline::ParaformerOnline + InitCache   (:12-62, 347-384)
+ *   pfhip_stream_forward  <-> ParaformerOnline::Forward(din, len, input_finished) (:525-601), i.e.
+ *                             ExtractFeats/OnlineLfrCmvn (:147-238), x*sqrt(d)+GetPosEmb (:549-555, 240-268),
+ *                             AddOverlapChunk (:397-413), ForwardChunk = encoder Run + CifSearch + decoder Run
+ *                             + OnlineGreedySearch (:415-523, 270-345; paraformer.cpp:362-371)
+ *   pfhip_stream_reset    <-> Reset + ResetCache (:386-395)
+ * token_ids receives the ids of the tokens this call emitted (the reference returns their text); at most
+ * 32000 samples per call (the 2-pass server sends 9600, websocket-server-2pass.cpp:135-148). */
+typedef struct pfhip_stream pfhip_stream;
+pfhip_status pfhip_stream_create(pfhip_model* m, const int* chunk_size /* [3] or NULL = {5,10,5} */,
+                                 pfhip_stream** out);
+void pfhip_stream_destroy(pfhip_stream* s);
+pfhip_status pfhip_stream_reset(pfhip_stream* s);
+pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_samples, int input_finished,
+                                  int32_t* token_ids, int cap, int* n_tokens);
+/* Inspection of the LAST encoder window of the last call: "chunk" [n,560], "enc" [n,d], "alphas" [n],
+ * "emb" [fires,d], "logp" [fires,vocab] (log-probs are only kept after pfhip_stream_set_debug(s,1)). */
+pfhip_status pfhip_stream_set_debug(pfhip_stream* s, int on);
+pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* dst, size_t cap_floats,
+                                     size_t* n_out);
+
 /* ---- inspection (parity tests) -----------------------------------------------------------------
  * Copies a named intermediate of the LAST forward to host: "feats" [M,560], "enc" [M,d],
  * "alphas" [M] (without the tail slot), "emb" [sum fires, d], "logp" [sum fires, vocab].

@@ -1,0 +1,97 @@
+"""GPU: the chunk-streaming path (pfhip_stream_*) against the streaming oracle, call by call."""
+import numpy as np
+import pytest
+
+from conftest import synth_pcm
+from oracle import paraformer as P
+from oracle import paraformer_online as PO
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def small(pkg, weights_mod):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    cfg = weights_mod.small_config(enc_layers=3, dec_layers=2, vocab=517)
+    man, blob = weights_mod.synth_weights(cfg, seed=77)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    yield pkg, model, P.Weights(man, blob)
+    model.close()
+
+
+def run_both(pkg, model, W, pcm, steps):
+    """steps: list of (n_samples, input_finished).  Returns per-call (oracle ids, hip ids) and checks tensors."""
+    on = PO.ParaformerOnline(W)
+    hip = pkg.ParaformerOnlineHip(model)
+    hip.set_debug(True)
+    pos = 0
+    for n, fin in steps:
+        seg = pcm[pos:pos + n]
+        pos += n
+        before = len(on.chunk_log)
+        ref_ids = on.Forward(seg, fin)
+        got_ids = hip.Forward(seg, input_finished=fin)
+        assert got_ids == ref_ids, (n, fin, got_ids, ref_ids)
+        if len(on.chunk_log) > before:
+            last = on.chunk_log[-1]
+            nrow = last["feats"].shape[0]
+            chunk = hip.get_tensor("chunk", 128 * 560).reshape(-1, 560)
+            assert chunk.shape[0] == nrow
+            assert np.abs(chunk - last["feats"]).max() < 2e-3          # rows are x sqrt(512) ~ 22.6 * 2e-5
+            enc = hip.get_tensor("enc", 128 * 512).reshape(-1, 512)
+            assert np.abs(enc - last["enc"]).max() < 1e-3
+            alphas = hip.get_tensor("alphas", 128)
+            assert np.abs(alphas - last["alphas"]).max() < 1e-4
+            if last["logp"] is not None:
+                logp = hip.get_tensor("logp", 128 * W.cfg["vocab"]).reshape(-1, W.cfg["vocab"])
+                assert logp.shape == last["logp"].shape
+                assert np.abs(logp - last["logp"]).max() < 1e-3       # BASELINE.json tolerance
+    hip.close()
+    return on
+
+
+def test_stream_600ms_steps_then_final_full_chunk(small):
+    pkg, model, W = small
+    rng = np.random.default_rng(11)
+    pcm = synth_pcm(3, 9600 * 6, rng)
+    on = run_both(pkg, model, W, pcm, [(9600, False)] * 5 + [(9600, True)])
+    assert sum(len(c["ids"]) for c in on.chunk_log) > 0
+
+
+def test_stream_short_final_flush_and_restart(small):
+    pkg, model, W = small
+    rng = np.random.default_rng(12)
+    pcm = synth_pcm(4, 9600 * 3 + 700 + 9600 * 2, rng)
+    # 3 chunks, a 700-sample final (flushes the look-back cache, :532-540), then a new utterance on the same stream
+    run_both(pkg, model, W, pcm, [(9600, False)] * 3 + [(700, True), (9600, False), (9600, True)])
+
+
+def test_stream_final_partial_chunk(small):
+    pkg, model, W = small
+    rng = np.random.default_rng(13)
+    pcm = synth_pcm(5, 9600 * 2 + 4000, rng)
+    run_both(pkg, model, W, pcm, [(9600, False), (9600, False), (4000, True)])       # nr + 5 <= 10 branch (:557-559)
+
+
+def test_stream_irregular_steps(small):
+    pkg, model, W = small
+    rng = np.random.default_rng(14)
+    pcm = synth_pcm(6, 60000, rng)
+    run_both(pkg, model, W, pcm, [(8000, False), (12345, False), (9600, False), (16000, False), (14055, True)])
+
+
+def test_two_streams_do_not_interfere(small):
+    pkg, model, W = small
+    rng = np.random.default_rng(15)
+    a, b = synth_pcm(7, 9600 * 3, rng), synth_pcm(8, 9600 * 3, rng)
+    ra, rb = PO.ParaformerOnline(W), PO.ParaformerOnline(W)
+    ha, hb = pkg.ParaformerOnlineHip(model), pkg.ParaformerOnlineHip(model)
+    for k in range(3):
+        fin = k == 2
+        sa, sb = a[k * 9600:(k + 1) * 9600], b[k * 9600:(k + 1) * 9600]
+        assert ha.Forward(sa, input_finished=fin) == ra.Forward(sa, fin)
+        assert hb.Forward(sb, input_finished=fin) == rb.Forward(sb, fin)
+    ha.close()
+    hb.close()

@@ -210,6 +210,73 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   }
 }
 
+// ---- skinny GEMM for the chunk-streaming path (M <= 64 rows: one 20-row encoder window, a few tokens) ----
+// Weight-streaming-bound: every weight is read once per chunk, so the job is to keep many independent
+// 16-byte loads in flight, not to tile for reuse.  One block = one 32-column strip of W over the full K,
+// its 4 waves split K four ways (each lane streams W[n][k..k+3] straight into VGPRs, deep unrolled, no LDS
+// staging: cdna_hip_programming.md "GEMV / M <= 16" row), partial 32x32 tiles are summed through LDS and
+// written with the same fused epilogue.  Activations (<= 64 x K, L2-resident) are read the same way.
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ W, int ldw, float* C,
+                                                              int ldc, const float* __restrict__ bias,
+                                                              const float* R1, int ldr1, const float* R2,
+                                                              int ldr2, int M, int N, int K, int relu) {
+  __shared__ float red[4][32 * 33];
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int kq = K >> 2;                       // K % 32 == 0 -> each wave's share is a multiple of 8
+  const int kbeg = wave * kq, kend = kbeg + kq;
+  const float* ap = A + (size_t)(m0 + r) * lda + 4 * h;      // rows up to the 128-row allocation exist
+  const float* wp = W + (size_t)(n0 + r) * ldw + 4 * h;      // rows up to the 128-row padding are readable
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  int k = kbeg;
+  for (; k + 32 <= kend; k += 32) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const float4*>(ap + k + 8 * u);
+      b[u] = *reinterpret_cast<const float4*>(wp + k + 8 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+  for (; k < kend; k += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + k);
+    const float4 b = *reinterpret_cast<const float4*>(wp + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  // D[i = activation row][j = weight column]: col j = lane&31, row i = (e&3) + 8*(e>>2) + 4*h
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
+  __syncthreads();
+  const int row = tid >> 3, c0 = (tid & 7) * 4;
+  const int grow = m0 + row;
+  if (grow >= M) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = n0 + c0 + q;
+    if (col >= N) break;
+    const int o = row * 33 + c0 + q;
+    float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (bias) v += bias[col];
+    if (R1) v += R1[(size_t)grow * ldr1 + col];
+    if (R2) v += R2[(size_t)grow * ldr2 + col];
+    if (relu) v = fmaxf(v, 0.f);
+    C[(size_t)grow * ldc + col] = v;
+  }
+}
+
 template <bool GUARD>
 void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                     const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu,
@@ -249,6 +316,12 @@ void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, int M,
                      int N, int K, bool relu, bool guard, hipStream_t s) {
   if (M <= 0 || N <= 0) return;
+  if (M <= 64) {   // chunk-streaming shapes: weight-streaming kernel (always bounds-checked)
+    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
+    hipLaunchKernelGGL(gemm_f32_skinny_kernel, grid, block, 0, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N,
+                       K, relu ? 1 : 0);
+    return;
+  }
   if (guard) launch_variant<true>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
   else launch_variant<false>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
 }

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
+    "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
 ]
 
 
@@ -87,6 +88,12 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_stream_forward.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
     lib.pfhip_stream_set_debug.argtypes = [vp, ci]
     lib.pfhip_stream_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.pfhip_vad_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    lib.pfhip_vad_destroy.argtypes = [vp]
+    lib.pfhip_vad_destroy.restype = None
+    lib.pfhip_vad_reset.argtypes = [vp]
+    lib.pfhip_vad_num_classes.argtypes = [vp]
+    lib.pfhip_vad_forward.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci)]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -322,3 +329,44 @@ class ParaformerOnlineHip:
         n = ctypes.c_size_t(0)
         _check(self._lib, self._lib.pfhip_stream_get_tensor(self._h, name.encode(), buf.ctypes.data, cap_floats, ctypes.byref(n)))
         return buf[:n.value]
+
+
+class FsmnVadHip:
+    """Host-side mirror of `funasr::FsmnVad` up to the frame scores (onnxruntime/src/fsmn-vad.cpp): InitVad,
+    Forward(waves, is_final) -> probs [T, classes], InitCache.  The E2EVadModel post-processing state machine
+    (e2e-vad.h) that turns scores into segments is host logic above this path."""
+
+    def __init__(self):
+        self._lib = load_lib()
+        self._h = ctypes.c_void_p()
+
+    def InitVad(self, vad_model, vad_cmvn=None, vad_config=None, thread_num=1, device=0):
+        man, blob = vad_model
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        _check(self._lib, self._lib.pfhip_vad_create_from_memory(blob.ctypes.data, blob.nbytes, json.dumps(man).encode(),
+                                                                 device, ctypes.byref(self._h)))
+        return self
+
+    def close(self):
+        if self._h:
+            self._lib.pfhip_vad_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def InitCache(self):
+        _check(self._lib, self._lib.pfhip_vad_reset(self._h))
+
+    def Forward(self, waves, is_final=False):
+        x = np.ascontiguousarray(waves, dtype=np.float32)
+        C = self._lib.pfhip_vad_num_classes(self._h)
+        cap = (max(0, (x.size - 400) // 160 + 1) + 1) * C
+        probs = np.zeros(cap, np.float32)
+        n = ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_vad_forward(self._h, x.ctypes.data if x.size else None, int(x.size),
+                                                      1 if is_final else 0, probs.ctypes.data, cap, ctypes.byref(n)))
+        return probs[:n.value * C].reshape(n.value, C)

@@ -213,32 +213,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
 // ---- skinny GEMM for the chunk-streaming path (M <= 64 rows: one 20-row encoder window, a few tokens) ----
 // Weight-streaming-bound: every weight is read once per chunk, so the job is to keep many independent
 // 16-byte loads in flight, not to tile for reuse.  One block = one 32-column strip of W over the full K,
-// its 4 waves split K four ways (each lane streams W[n][k..k+3] straight into VGPRs, deep unrolled, no LDS
+// its 16 waves split K sixteen ways (each lane streams W[n][k..k+3] straight into VGPRs, deep unrolled, no LDS
 // staging: cdna_hip_programming.md "GEMV / M <= 16" row), partial 32x32 tiles are summed through LDS and
 // written with the same fused epilogue.  Activations (<= 64 x K, L2-resident) are read the same way.
-__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __restrict__ A, int lda,
-                                                              const float* __restrict__ W, int ldw, float* C,
-                                                              int ldc, const float* __restrict__ bias,
-                                                              const float* R1, int ldr1, const float* R2,
-                                                              int ldr2, int M, int N, int K, int relu) {
-  __shared__ float red[4][32 * 33];
+constexpr int kSkinnyWaves = 16;
+
+__global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(const float* __restrict__ A, int lda,
+                                                               const float* __restrict__ W, int ldw, float* C,
+                                                               int ldc, const float* __restrict__ bias,
+                                                               const float* R1, int ldr1, const float* R2,
+                                                               int ldr2, int M, int N, int K, int relu) {
+  __shared__ float red[kSkinnyWaves][32 * 33];
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int kq = K >> 2;                       // K % 32 == 0 -> each wave's share is a multiple of 8
-  const int kbeg = wave * kq, kend = kbeg + kq;
+  // K is split 16 ways in units of 8 (one MFMA k-block): K = 512 -> 4 loads per wave, all in flight at once
+  const int nkb = K >> 3;
+  const int per = (nkb + kSkinnyWaves - 1) / kSkinnyWaves;
+  const int kb0 = wave * per;
+  const int kb1 = kb0 + per < nkb ? kb0 + per : nkb;
   const float* ap = A + (size_t)(m0 + r) * lda + 4 * h;      // rows up to the 128-row allocation exist
   const float* wp = W + (size_t)(n0 + r) * ldw + 4 * h;      // rows up to the 128-row padding are readable
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  int k = kbeg;
-  for (; k + 32 <= kend; k += 32) {
+  int kb = kb0;
+  for (; kb + 8 <= kb1; kb += 8) {
+    float4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = *reinterpret_cast<const float4*>(ap + 8 * (kb + u));
+      b[u] = *reinterpret_cast<const float4*>(wp + 8 * (kb + u));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+  if (kb + 4 <= kb1) {
     float4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      a[u] = *reinterpret_cast<const float4*>(ap + k + 8 * u);
-      b[u] = *reinterpret_cast<const float4*>(wp + k + 8 * u);
+      a[u] = *reinterpret_cast<const float4*>(ap + 8 * (kb + u));
+      b[u] = *reinterpret_cast<const float4*>(wp + 8 * (kb + u));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -247,10 +267,11 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __res
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
     }
+    kb += 4;
   }
-  for (; k < kend; k += 8) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + k);
-    const float4 b = *reinterpret_cast<const float4*>(wp + k);
+  for (; kb < kb1; ++kb) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + 8 * kb);
+    const float4 b = *reinterpret_cast<const float4*>(wp + 8 * kb);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
@@ -260,21 +281,18 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __res
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
   __syncthreads();
-  const int row = tid >> 3, c0 = (tid & 7) * 4;
-  const int grow = m0 + row;
-  if (grow >= M) return;
+  const int row = tid >> 5, col = tid & 31;          // 1024 threads = the 32 x 32 tile
+  const int grow = m0 + row, gcol = n0 + col;
+  if (grow >= M || gcol >= N) return;
+  const int o = row * 33 + col;
+  float v = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int col = n0 + c0 + q;
-    if (col >= N) break;
-    const int o = row * 33 + c0 + q;
-    float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-    if (bias) v += bias[col];
-    if (R1) v += R1[(size_t)grow * ldr1 + col];
-    if (R2) v += R2[(size_t)grow * ldr2 + col];
-    if (relu) v = fmaxf(v, 0.f);
-    C[(size_t)grow * ldc + col] = v;
-  }
+  for (int w2 = 0; w2 < kSkinnyWaves; ++w2) v += red[w2][o];
+  if (bias) v += bias[gcol];
+  if (R1) v += R1[(size_t)grow * ldr1 + gcol];
+  if (R2) v += R2[(size_t)grow * ldr2 + gcol];
+  if (relu) v = fmaxf(v, 0.f);
+  C[(size_t)grow * ldc + gcol] = v;
 }
 
 template <bool GUARD>
@@ -317,7 +335,7 @@ void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C,
                      int N, int K, bool relu, bool guard, hipStream_t s) {
   if (M <= 0 || N <= 0) return;
   if (M <= 64) {   // chunk-streaming shapes: weight-streaming kernel (always bounds-checked)
-    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
+    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(1024);
     hipLaunchKernelGGL(gemm_f32_skinny_kernel, grid, block, 0, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N,
                        K, relu ? 1 : 0);
     return;

@@ -59,6 +59,12 @@ struct Config {
   int sample_rate = 16000;
 };
 
+struct FrontendTables {
+  float* d_window = nullptr; double* d_tw = nullptr; int* d_mel_off = nullptr; int* d_mel_size = nullptr;
+  float* d_mel_w = nullptr;
+};
+pfhip_status build_frontend_tables(int n_mels, int sample_rate, FrontendTables* ft);   // pfhip.cpp
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct ProfRec { int cls; hipEvent_t e0, e1; };

@@ -104,4 +104,14 @@ void launch_cif_stream(const float* enc, int lde, const float* alphas, int n, in
 void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, float* cache, int N,
                         int C, hipStream_t s);
 
+// ---- FSMN-VAD pieces --------------------------------------------------------------
+// Generic LfrCmvn over raw fbank frames fb [F, n_mels] -> out [T = ceil(F/n), ldo] (columns >= m*n_mels zeroed).
+void launch_lfr_cmvn(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,
+                     float* out, int ldo, hipStream_t s);
+// Memory block with left order 20: out = p + causal depthwise conv over [cache(19 rows); p]; cache_out (may be
+// null) receives the last 19 rows of [cache_in; p] and must not alias cache_in.
+void launch_fsmn_causal20(const float* p, int ldp, const float* w, const float* cache_in, float* cache_out, float* out,
+                          int ldo, int T, int C, hipStream_t s);
+void launch_softmax_rows(const float* x, int ldx, int M, int N, float* y, hipStream_t s);
+
 }  // namespace pfhip

@@ -76,6 +76,32 @@ pfhip_status upload(T** dst, const std::vector<T>& v) {
   return PFHIP_OK;
 }
 
+}  // namespace
+
+namespace pfhip_detail {
+// knf tables exactly as the reference's host code computes them (feature-window.cc:33-42,
+// mel-computations.cc:107-196) + the FFT twiddles of the device kernel.
+pfhip_status build_frontend_tables(int n_mels, int sample_rate, FrontendTables* ft) {
+  std::vector<float> win(400);
+  const double a = 2.0 * M_PI / (400 - 1);
+  for (int i = 0; i < 400; ++i) win[i] = (float)(0.54 - 0.46 * cos(a * (double)i));
+  std::vector<double> tw(512);
+  for (int k = 0; k < 256; ++k) { tw[2 * k] = cos(2.0 * M_PI * k / 512.0); tw[2 * k + 1] = -sin(2.0 * M_PI * k / 512.0); }
+  std::vector<int> moff, msz; std::vector<float> mw;
+  build_mel(n_mels, (float)sample_rate, moff, msz, mw);
+  for (int b = 0; b < n_mels; ++b)
+    if (msz[b] > pfhip::kMelW) return fail(PFHIP_ERR_UNSUPPORTED, "mel triangle wider than kMelW");
+  pfhip_status st;
+  if ((st = upload(&ft->d_window, win)) || (st = upload(&ft->d_tw, tw)) || (st = upload(&ft->d_mel_off, moff)) ||
+      (st = upload(&ft->d_mel_size, msz)) || (st = upload(&ft->d_mel_w, mw)))
+    return st;
+  return PFHIP_OK;
+}
+}  // namespace pfhip_detail
+
+namespace {
+using namespace pfhip_detail;
+
 pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
                          pfhip_model** out) {
   if (!blob || !manifest_json || !out) return fail(PFHIP_ERR_ARG, "null argument");
@@ -200,24 +226,17 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   }
   // ---- front-end tables ------------------------------------------------------------------------------
   {
-    std::vector<float> win(400);
-    const double a = 2.0 * M_PI / (400 - 1);                       // feature-window.cc:33-42
-    for (int i = 0; i < 400; ++i) win[i] = (float)(0.54 - 0.46 * cos(a * (double)i));
-    std::vector<double> tw(512);
-    for (int k = 0; k < 256; ++k) { tw[2 * k] = cos(2.0 * M_PI * k / 512.0); tw[2 * k + 1] = -sin(2.0 * M_PI * k / 512.0); }
-    std::vector<int> moff, msz; std::vector<float> mw;
-    build_mel(c.n_mels, (float)c.sample_rate, moff, msz, mw);
-    for (int b = 0; b < c.n_mels; ++b)
-      if (msz[b] > pfhip::kMelW) return fail(PFHIP_ERR_UNSUPPORTED, "mel triangle wider than kMelW");
+    pfhip_detail::FrontendTables ft;
+    pfhip_status st = pfhip_detail::build_frontend_tables(c.n_mels, c.sample_rate, &ft);
+    if (st) return st;
+    m->d_window = ft.d_window; m->d_tw = ft.d_tw; m->d_mel_off = ft.d_mel_off; m->d_mel_size = ft.d_mel_size;
+    m->d_mel_w = ft.d_mel_w;
     const int half = m->feat_dim / 2;
     std::vector<float> inv(half);
     // paraformer-online.cpp:247-252: float scale, exp() in double of a float argument, stored to float
     const float scale = m->feat_dim == 560 ? -0.0330119726594128f : (float)(-std::log(10000.0) / (half - 1));
     for (int i = 0; i < half; ++i) inv[i] = (float)exp((double)(i * scale));
-    pfhip_status st;
-    if ((st = upload(&m->d_window, win)) || (st = upload(&m->d_tw, tw)) || (st = upload(&m->d_mel_off, moff)) ||
-        (st = upload(&m->d_mel_size, msz)) || (st = upload(&m->d_mel_w, mw)) || (st = upload(&m->d_inv_ts, inv)))
-      return st;
+    if ((st = upload(&m->d_inv_ts, inv))) return st;
   }
   HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   for (auto& kv : m->t) kv.second.h = nullptr;

@@ -1,0 +1,225 @@
+// FSMN-VAD forward on MI355X — the C ABI's pfhip_vad_* family.
+// Replaces FsmnVad::FbankKaldi + LfrCmvn + Forward (onnxruntime/src/fsmn-vad.cpp:137-152, 198-238, 72-135): PCM ->
+// frame scores [T, 248] with the four [128 x 19] FSMN caches carried in HBM.  The network is causal, so a whole
+// file goes through in ONE pass of ~12 launches instead of the reference's 1-s slices (600 Runs per 10 minutes,
+// onnxruntime/src/audio.cpp:1183-1196); slice-wise calls give the same scores because the caches carry over.
+// Linear layers run on the same fp32 MFMA GEMM kernels as the ASR model; their odd widths (140, 250, 248) are
+// zero-padded once at load ([N up to 128][K up to 32]) so that pad outputs are exact zeros.
+#include <memory>
+
+#include "internal.h"
+#include "json_min.h"
+
+using namespace pfhip_detail;
+
+namespace {
+struct Lin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0, Np = 0, Kp = 0; };
+}
+
+struct pfhip_vad {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  int n_mels = 80, lfr_m = 5, lfr_n = 1, input_dim = 400, proj = 128, lorder = 20, layers = 4, n_out = 248, linear = 250;
+  FrontendTables ft;
+  float *d_mean = nullptr, *d_istd = nullptr;
+  Lin in1, in2, out1, out2;
+  std::vector<Lin> blk_linear, blk_affine;
+  std::vector<float*> fsmn_w;
+  Buf pcm, fb, feats, a, b, p, f, probs, meta, cache[2];
+  int cache_cur = 0;
+  int* h_pin = nullptr;
+};
+
+namespace {
+
+pfhip_status pack_linear(const float* w, const float* bias, int N, int K, Lin* out) {
+  out->N = N; out->K = K; out->Np = round_up(N, 128); out->Kp = round_up(K, 32);
+  std::vector<float> pw((size_t)out->Np * out->Kp, 0.f), pb((size_t)out->Np, 0.f);
+  for (int n = 0; n < N; ++n) std::memcpy(&pw[(size_t)n * out->Kp], w + (size_t)n * K, sizeof(float) * K);
+  if (bias) std::memcpy(pb.data(), bias, sizeof(float) * N);
+  HIP_TRY(hipMalloc((void**)&out->w, pw.size() * 4));
+  HIP_TRY(hipMemcpy(out->w, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&out->b, pb.size() * 4));
+  HIP_TRY(hipMemcpy(out->b, pb.data(), pb.size() * 4, hipMemcpyHostToDevice));
+  return PFHIP_OK;
+}
+
+void lin_gemm(hipStream_t s, const Lin& l, const float* A, int lda, float* C, int ldc, int M, bool relu) {
+  pfhip::launch_gemm_f32(A, lda, l.w, l.Kp, C, ldc, l.b, nullptr, 0, nullptr, 0, M, l.Np, l.Kp, relu, false, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+pfhip_status pfhip_vad_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
+                                          pfhip_vad** out) {
+  last_error().clear();
+  if (!blob || !manifest_json || !out) return fail(PFHIP_ERR_ARG, "null argument");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(PFHIP_ERR_ARG, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  pfhip::JValue man;
+  try { man = pfhip::JParser(manifest_json).parse(); }
+  catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
+  const pfhip::JValue* jc = man.get("config");
+  const pfhip::JValue* jt = man.get("tensors");
+  if (!jc || !jt || jt->kind != pfhip::JValue::OBJ) return fail(PFHIP_ERR_FORMAT, "manifest needs config and tensors");
+  std::unique_ptr<pfhip_vad> v(new pfhip_vad);
+  v->device = device;
+  v->n_mels = (int)jc->number("n_mels", 80);
+  v->lfr_m = (int)jc->number("lfr_m", 5);
+  v->lfr_n = (int)jc->number("lfr_n", 1);
+  v->input_dim = (int)jc->number("input_dim", 400);
+  v->proj = (int)jc->number("proj", 128);
+  v->lorder = (int)jc->number("lorder", 20);
+  v->layers = (int)jc->number("layers", 4);
+  v->n_out = (int)jc->number("n_out", 248);
+  v->linear = (int)jc->number("linear", 250);
+  const int affine = (int)jc->number("affine", 140), out_affine = (int)jc->number("out_affine", 140);
+  if (v->n_mels != 80 || v->input_dim != v->n_mels * v->lfr_m || v->lorder != 20 || v->proj % 4 || v->layers < 1 ||
+      v->layers > 16)
+    return fail(PFHIP_ERR_UNSUPPORTED, "FSMN-VAD kernels need 80 mels, left order 20");
+  const float* hb = static_cast<const float*>(blob);
+  auto get = [&](const std::string& name, std::vector<int> shape, const float** p) -> bool {
+    const pfhip::JValue* t = jt->get(name);
+    if (!t) { last_error() = "missing tensor " + name; return false; }
+    const pfhip::JValue* sh = t->get("shape");
+    const pfhip::JValue* of = t->get("offset");
+    if (!sh || !of || sh->arr.size() != shape.size()) { last_error() = "tensor " + name + " malformed"; return false; }
+    size_t n = 1;
+    for (size_t i = 0; i < shape.size(); ++i) {
+      if ((int)sh->arr[i].num != shape[i]) { last_error() = "tensor " + name + " has unexpected shape"; return false; }
+      n *= (size_t)shape[i];
+    }
+    const size_t off = (size_t)of->num;
+    if (off % 4 || off + n * 4 > blob_bytes) { last_error() = "tensor " + name + " out of blob"; return false; }
+    *p = hb + off / 4;
+    return true;
+  };
+  auto lin = [&](const std::string& name, int N, int K, bool bias, Lin* l) -> pfhip_status {
+    const float *w = nullptr, *b = nullptr;
+    if (!get(name + ".w", {N, K}, &w)) return PFHIP_ERR_FORMAT;
+    if (bias && !get(name + ".b", {N}, &b)) return PFHIP_ERR_FORMAT;
+    return pack_linear(w, b, N, K, l);
+  };
+  pfhip_status st;
+  const float *mean = nullptr, *istd = nullptr;
+  if (!get("cmvn.mean", {v->input_dim}, &mean) || !get("cmvn.istd", {v->input_dim}, &istd)) return PFHIP_ERR_FORMAT;
+  HIP_TRY(hipMalloc((void**)&v->d_mean, v->input_dim * 4));
+  HIP_TRY(hipMemcpy(v->d_mean, mean, v->input_dim * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&v->d_istd, v->input_dim * 4));
+  HIP_TRY(hipMemcpy(v->d_istd, istd, v->input_dim * 4, hipMemcpyHostToDevice));
+  if ((st = lin("in1", affine, v->input_dim, true, &v->in1)) || (st = lin("in2", v->linear, affine, true, &v->in2))) return st;
+  v->blk_linear.resize(v->layers); v->blk_affine.resize(v->layers); v->fsmn_w.assign(v->layers, nullptr);
+  for (int i = 0; i < v->layers; ++i) {
+    const std::string p = "blk." + std::to_string(i) + ".";
+    if ((st = lin(p + "linear", v->proj, v->linear, false, &v->blk_linear[i])) ||
+        (st = lin(p + "affine", v->linear, v->proj, true, &v->blk_affine[i])))
+      return st;
+    const float* fw = nullptr;
+    if (!get(p + "fsmn.w", {v->proj, v->lorder}, &fw)) return PFHIP_ERR_FORMAT;
+    HIP_TRY(hipMalloc((void**)&v->fsmn_w[i], (size_t)v->proj * v->lorder * 4));
+    HIP_TRY(hipMemcpy(v->fsmn_w[i], fw, (size_t)v->proj * v->lorder * 4, hipMemcpyHostToDevice));
+  }
+  if ((st = lin("out1", out_affine, v->linear, true, &v->out1)) || (st = lin("out2", v->n_out, out_affine, true, &v->out2))) return st;
+  if ((st = build_frontend_tables(v->n_mels, 16000, &v->ft))) return st;
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(v->cache[i].ensure((size_t)v->layers * 19 * v->proj * 4));
+    HIP_TRY(hipMemset(v->cache[i].p, 0, (size_t)v->layers * 19 * v->proj * 4));
+  }
+  HIP_TRY(v->meta.ensure(256));
+  HIP_TRY(hipHostMalloc((void**)&v->h_pin, 256, hipHostMallocDefault));
+  HIP_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+  *out = v.release();
+  return PFHIP_OK;
+}
+
+void pfhip_vad_destroy(pfhip_vad* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  (void)hipDeviceSynchronize();
+  for (Buf* b : {&v->pcm, &v->fb, &v->feats, &v->a, &v->b, &v->p, &v->f, &v->probs, &v->meta, &v->cache[0], &v->cache[1]}) b->release();
+  auto fl = [](Lin& l) { if (l.w) (void)hipFree(l.w); if (l.b) (void)hipFree(l.b); };
+  fl(v->in1); fl(v->in2); fl(v->out1); fl(v->out2);
+  for (auto& l : v->blk_linear) fl(l);
+  for (auto& l : v->blk_affine) fl(l);
+  for (float* p : v->fsmn_w) if (p) (void)hipFree(p);
+  for (void* p : {(void*)v->d_mean, (void*)v->d_istd, (void*)v->ft.d_window, (void*)v->ft.d_tw, (void*)v->ft.d_mel_off,
+                  (void*)v->ft.d_mel_size, (void*)v->ft.d_mel_w})
+    if (p) (void)hipFree(p);
+  if (v->h_pin) (void)hipHostFree(v->h_pin);
+  if (v->stream) (void)hipStreamDestroy(v->stream);
+  delete v;
+}
+
+pfhip_status pfhip_vad_reset(pfhip_vad* v) {
+  last_error().clear();
+  if (!v) return fail(PFHIP_ERR_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(v->mu);
+  HIP_TRY(hipSetDevice(v->device));
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetAsync(v->cache[i].p, 0, (size_t)v->layers * 19 * v->proj * 4, v->stream));
+  HIP_TRY(hipStreamSynchronize(v->stream));
+  return PFHIP_OK;
+}
+
+int pfhip_vad_num_classes(const pfhip_vad* v) { return v ? v->n_out : 0; }
+
+pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
+                               size_t cap_floats, int* n_frames) {
+  last_error().clear();
+  if (!v || n_samples < 0 || (n_samples > 0 && !pcm) || !n_frames) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(v->mu);
+  HIP_TRY(hipSetDevice(v->device));
+  hipStream_t s = v->stream;
+  const int F = n_samples < 400 ? 0 : 1 + (n_samples - 400) / 160;
+  const int T = (F + v->lfr_n - 1) / v->lfr_n;               // fsmn-vad.cpp:202
+  *n_frames = T;
+  if (T == 0) return PFHIP_OK;                                // fsmn-vad.cpp:245-247
+  if ((size_t)T * v->n_out > cap_floats && probs) return fail(PFHIP_ERR_CAPACITY, "probs buffer too small");
+  const int Tp = round_up(T, 128);
+  HIP_TRY(v->pcm.ensure((size_t)n_samples * 4));
+  HIP_TRY(v->fb.ensure((size_t)F * 80 * 4));
+  HIP_TRY(v->feats.ensure((size_t)Tp * v->in1.Kp * 4));
+  HIP_TRY(v->a.ensure((size_t)Tp * 256 * 4));
+  HIP_TRY(v->b.ensure((size_t)Tp * 256 * 4));
+  HIP_TRY(v->p.ensure((size_t)Tp * 128 * 4));
+  HIP_TRY(v->f.ensure((size_t)Tp * 128 * 4));
+  HIP_TRY(v->probs.ensure((size_t)T * v->n_out * 4));
+  if (v->in1.Np > 256 || v->in2.Np > 256 || v->out1.Np > 256 || v->out2.Np > 256 || v->proj > 128)
+    return fail(PFHIP_ERR_UNSUPPORTED, "FSMN-VAD layer wider than the workspace");
+  HIP_TRY(hipMemcpyAsync(v->pcm.p, pcm, (size_t)n_samples * 4, hipMemcpyHostToDevice, s));
+  {
+    int64_t* h64 = reinterpret_cast<int64_t*>(v->h_pin);
+    h64[0] = 0;
+    int* hm = v->h_pin + 2;
+    hm[0] = 0; hm[1] = F; hm[2] = F;
+    HIP_TRY(hipMemcpyAsync(v->meta.p, v->h_pin, 32, hipMemcpyHostToDevice, s));
+  }
+  pfhip::FbankTables tb{v->ft.d_window, v->ft.d_tw, v->ft.d_mel_off, v->ft.d_mel_size, v->ft.d_mel_w, v->d_mean, v->d_istd};
+  pfhip::launch_fbank_frames(v->pcm.f(), reinterpret_cast<int64_t*>(v->meta.p), v->meta.i() + 2, v->meta.i() + 4, F, tb,
+                             v->fb.f(), s);
+  pfhip::launch_lfr_cmvn(v->fb.f(), F, T, v->lfr_m, v->lfr_n, v->n_mels, v->d_mean, v->d_istd, v->feats.f(), v->in1.Kp, s);
+  lin_gemm(s, v->in1, v->feats.f(), v->in1.Kp, v->a.f(), 256, T, false);
+  lin_gemm(s, v->in2, v->a.f(), 256, v->b.f(), 256, T, true);
+  const float* cin = v->cache[v->cache_cur].f();
+  float* cout = v->cache[v->cache_cur ^ 1].f();
+  for (int i = 0; i < v->layers; ++i) {
+    lin_gemm(s, v->blk_linear[i], v->b.f(), 256, v->p.f(), 128, T, false);
+    pfhip::launch_fsmn_causal20(v->p.f(), 128, v->fsmn_w[i], cin + (size_t)i * 19 * v->proj,
+                                is_final ? nullptr : cout + (size_t)i * 19 * v->proj, v->f.f(), 128, T, v->proj, s);
+    lin_gemm(s, v->blk_affine[i], v->f.f(), 128, v->b.f(), 256, T, true);
+  }
+  lin_gemm(s, v->out1, v->b.f(), 256, v->a.f(), 256, T, false);
+  lin_gemm(s, v->out2, v->a.f(), 256, v->b.f(), 256, T, false);
+  pfhip::launch_softmax_rows(v->b.f(), 256, T, v->n_out, v->probs.f(), s);
+  if (!is_final) v->cache_cur ^= 1;                             // fsmn-vad.cpp:129-134: caches kept only if not final
+  if (probs) HIP_TRY(hipMemcpyAsync(probs, v->probs.p, (size_t)T * v->n_out * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return PFHIP_OK;
+}
+
+}  // extern "C"

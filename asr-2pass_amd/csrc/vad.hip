@@ -1,0 +1,123 @@
+// FSMN-VAD kernels: generic LFR+CMVN gather, the causal memory block (depthwise conv over
+// the `lorder` most recent frames with a (lorder-1)-frame cache), row softmax.  All HBM-bound and tiny next to
+// the ASR model: a 10-minute file is 60 000 frames x ~0.4 M MACs.
+#include "kernels.h"
+
+#include <math.h>
+
+namespace pfhip {
+namespace {
+
+// LfrCmvn (onnxruntime/src/fsmn-vad.cpp:198-238 == paraformer.cpp:421-461) for any (m, n): row i = frames
+// [i*n - (m-1)/2, ...) with the first / last frame replicated; out = (x + mean) * istd; pad columns zeroed.
+__global__ __launch_bounds__(128) void lfr_cmvn_kernel(const float* __restrict__ fb, int F, int T, int m, int n,
+                                                       int n_mels, const float* __restrict__ mean,
+                                                       const float* __restrict__ istd, float* __restrict__ out,
+                                                       int ldo) {
+  const int i = blockIdx.x;
+  if (i >= T) return;
+  const int D = m * n_mels, lp = (m - 1) / 2;
+  for (int c = threadIdx.x; c < ldo; c += blockDim.x) {
+    float v = 0.f;
+    if (c < D) {
+      const int j = c / n_mels, bin = c - j * n_mels;
+      int f = i * n + j - lp;
+      f = f < 0 ? 0 : (f > F - 1 ? F - 1 : f);
+      v = (fb[(size_t)f * n_mels + bin] + mean[c]) * istd[c];
+    }
+    out[(size_t)i * ldo + c] = v;
+  }
+}
+
+// out[t][c] = p[t][c] + sum_{j<K} w[c][j] * xcat[t+j][c], xcat = [cache (K-1 rows); p (T rows)].
+// Time is tiled (kTT rows per block) with a K-row register window per thread (4 channels each).
+template <int K>
+__global__ __launch_bounds__(64) void fsmn_causal_kernel(const float* __restrict__ p, int ldp,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ cache, float* __restrict__ out,
+                                                         int ldo, int T, int C) {
+  constexpr int kTT = 32;
+  const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int t0 = blockIdx.x * kTT;
+  if (t0 >= T) return;
+  float wk[4][K];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+    for (int j = 0; j < K; ++j) wk[ch][j] = w[(size_t)(c + ch) * K + j];
+  auto load_row = [&](int t) -> float4 {          // t relative to p; negative -> cache row (K-1+t)
+    if (t >= 0) return t < T ? *reinterpret_cast<const float4*>(p + (size_t)t * ldp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(cache + (size_t)(K - 1 + t) * C + c);
+  };
+  float4 win[K];
+#pragma unroll
+  for (int j = 0; j < K - 1; ++j) win[j + 1] = load_row(t0 - (K - 1) + j);
+  for (int s = 0; s < kTT; ++s) {
+    const int t = t0 + s;
+    if (t >= T) break;
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) win[j] = win[j + 1];
+    win[K - 1] = load_row(t);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      a.x += wk[0][j] * win[j].x; a.y += wk[1][j] * win[j].y;
+      a.z += wk[2][j] * win[j].z; a.w += wk[3][j] * win[j].w;
+    }
+    float4 o = win[K - 1];
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *reinterpret_cast<float4*>(out + (size_t)t * ldo + c) = o;
+  }
+}
+
+// new cache = last K-1 rows of [cache; p]
+__global__ __launch_bounds__(128) void fsmn_cache_update_kernel(const float* __restrict__ p, int ldp,
+                                                                const float* __restrict__ cache_in,
+                                                                float* __restrict__ cache_out, int T, int C,
+                                                                int K1) {
+  const int j = blockIdx.x;                       // row of the new cache, 0..K1-1
+  const int src = T - K1 + j;                     // row of p, negative -> old cache row K1 + src
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    cache_out[(size_t)j * C + c] = src >= 0 ? p[(size_t)src * ldp + c] : cache_in[(size_t)(K1 + src) * C + c];
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, int M, int N,
+                                                           float* __restrict__ y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float m = -INFINITY;
+  for (int c = lane; c < N; c += 64) m = fmaxf(m, xr[c]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += expf(xr[c] - m);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  for (int c = lane; c < N; c += 64) y[(size_t)row * N + c] = expf(xr[c] - m) / s;
+}
+
+}  // namespace
+
+void launch_lfr_cmvn(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,
+                     float* out, int ldo, hipStream_t s) {
+  if (T <= 0) return;
+  hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(T), dim3(128), 0, s, fb, F, T, m, n, n_mels, mean, istd, out, ldo);
+}
+
+void launch_fsmn_causal20(const float* p, int ldp, const float* w, const float* cache_in, float* cache_out, float* out,
+                          int ldo, int T, int C, hipStream_t s) {
+  if (T <= 0) return;
+  hipLaunchKernelGGL(fsmn_causal_kernel<20>, dim3((T + 31) / 32, (C + 255) / 256), dim3(64), 0, s, p, ldp, w, cache_in,
+                     out, ldo, T, C);
+  if (cache_out) hipLaunchKernelGGL(fsmn_cache_update_kernel, dim3(19), dim3(128), 0, s, p, ldp, cache_in, cache_out, T, C, 19);
+}
+
+void launch_softmax_rows(const float* x, int ldx, int M, int N, float* y, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, N, y);
+}
+
+}  // namespace pfhip

@@ -130,3 +130,50 @@ def load(path_prefix):
         man = json.load(f)
     blob = np.fromfile(path_prefix + ".bin", dtype=np.float32)
     return man, blob
+
+
+# ---- FSMN-VAD (UPSTREAM FunASR FSMN: 400-140-250-[128|250]x4-140-248) -----------------
+FSMN_VAD = dict(model="fsmn_vad", n_mels=80, lfr_m=5, lfr_n=1, input_dim=400, affine=140, linear=250, proj=128,
+                lorder=20, layers=4, out_affine=140, n_out=248)
+
+
+def vad_tensor_specs(cfg):
+    specs = [("cmvn.mean", [cfg["input_dim"]], ("const", -8.0)), ("cmvn.istd", [cfg["input_dim"]], ("const", 0.3))]
+
+    def lin(name, out_f, in_f, bias=True):
+        specs.append((name + ".w", [out_f, in_f], ("normal", 1.0 / math.sqrt(in_f))))
+        if bias:
+            specs.append((name + ".b", [out_f], ("normal", 0.05)))
+
+    lin("in1", cfg["affine"], cfg["input_dim"])
+    lin("in2", cfg["linear"], cfg["affine"])
+    for i in range(cfg["layers"]):
+        lin(f"blk.{i}.linear", cfg["proj"], cfg["linear"], bias=False)
+        specs.append((f"blk.{i}.fsmn.w", [cfg["proj"], cfg["lorder"]], ("normal", 1.0 / math.sqrt(cfg["lorder"]))))
+        lin(f"blk.{i}.affine", cfg["linear"], cfg["proj"])
+    lin("out1", cfg["out_affine"], cfg["linear"])
+    lin("out2", cfg["n_out"], cfg["out_affine"])
+    return specs
+
+
+def synth_generic(cfg, specs, seed):
+    tensors, off = {}, 0
+    for name, shape, _ in specs:
+        tensors[name] = {"shape": shape, "offset": off}
+        off += (int(np.prod(shape)) * 4 + ALIGN - 1) // ALIGN * ALIGN
+    man = {"config": cfg, "tensors": tensors, "total_bytes": off}
+    blob = np.zeros(off // 4, np.float32)
+    rng = np.random.default_rng(seed)
+    for name, shape, init in specs:
+        n = int(np.prod(shape))
+        o = tensors[name]["offset"] // 4
+        if init[0] == "normal":
+            blob[o:o + n] = rng.standard_normal(n, dtype=np.float32) * np.float32(init[1])
+        else:
+            blob[o:o + n] = np.float32(init[1])
+    return man, blob
+
+
+def synth_vad_weights(cfg=None, seed=4321):
+    cfg = dict(FSMN_VAD) if cfg is None else cfg
+    return synth_generic(cfg, vad_tensor_specs(cfg), seed)

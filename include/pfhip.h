@@ -123,6 +123,21 @@ pfhip_status pfhip_stream_set_debug(pfhip_stream* s, int on);
 pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* dst, size_t cap_floats,
                                      size_t* n_out);
 
+/* ---- FSMN-VAD forward ---------------------------------------------------------------------------
+ *   pfhip_vad_create_from_memory <-> FsmnVad::InitVad (ReadModel + LoadCmvn + InitCache, fsmn-vad.cpp:12-70, 258-263)
+ *   pfhip_vad_forward            <-> FsmnVad::FbankKaldi + LfrCmvn + Forward (fsmn-vad.cpp:137-152, 198-238, 72-135):
+ *                                    probs [T, n_classes] row-major (class 0 = silence, e2e-vad.h:103); the four
+ *                                    [128 x 19] caches stay in HBM and are advanced only when !is_final (:129-134)
+ *   pfhip_vad_reset              <-> FsmnVad::InitCache (:258-263) */
+typedef struct pfhip_vad pfhip_vad;
+pfhip_status pfhip_vad_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
+                                          pfhip_vad** out);
+void pfhip_vad_destroy(pfhip_vad* v);
+pfhip_status pfhip_vad_reset(pfhip_vad* v);
+int pfhip_vad_num_classes(const pfhip_vad* v);
+pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
+                               size_t cap_floats, int* n_frames);
+
 /* ---- inspection (parity tests) -----------------------------------------------------------------
  * Copies a named intermediate of the LAST forward to host: "feats" [M,560], "enc" [M,d],
  * "alphas" [M] (without the tail slot), "emb" [sum fires, d], "logp" [sum fires, vocab].

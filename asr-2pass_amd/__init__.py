@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
+    "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
 ]
 
 
@@ -94,6 +95,11 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_vad_reset.argtypes = [vp]
     lib.pfhip_vad_num_classes.argtypes = [vp]
     lib.pfhip_vad_forward.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci)]
+    lib.pfhip_punc_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    lib.pfhip_punc_destroy.argtypes = [vp]
+    lib.pfhip_punc_destroy.restype = None
+    lib.pfhip_punc_num_classes.argtypes = [vp]
+    lib.pfhip_punc_infer.argtypes = [vp, vp, ci, vp, vp]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -370,3 +376,41 @@ class FsmnVadHip:
         _check(self._lib, self._lib.pfhip_vad_forward(self._h, x.ctypes.data if x.size else None, int(x.size),
                                                       1 if is_final else 0, probs.ctypes.data, cap, ctypes.byref(n)))
         return probs[:n.value * C].reshape(n.value, C)
+
+
+class CTTransformerHip:
+    """Host-side mirror of `funasr::CTTransformer` for the forward only (onnxruntime/src/ct-transformer.cpp):
+    InitPunc, Infer(input_data) -> punctuation ids.  Tokenisation / sentence re-segmentation (AddPunc) are host
+    string logic above this path."""
+
+    def __init__(self):
+        self._lib = load_lib()
+        self._h = ctypes.c_void_p()
+
+    def InitPunc(self, punc_model, punc_config=None, token_file=None, thread_num=1, device=0):
+        man, blob = punc_model
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        _check(self._lib, self._lib.pfhip_punc_create_from_memory(blob.ctypes.data, blob.nbytes, json.dumps(man).encode(),
+                                                                  device, ctypes.byref(self._h)))
+        return self
+
+    def close(self):
+        if self._h:
+            self._lib.pfhip_punc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Infer(self, input_data, want_logits=False):
+        ids = np.ascontiguousarray(input_data, dtype=np.int32)
+        n = int(ids.size)
+        punc = np.zeros(n, np.int32)
+        C = self._lib.pfhip_punc_num_classes(self._h)
+        logits = np.zeros((n, C), np.float32) if want_logits else None
+        _check(self._lib, self._lib.pfhip_punc_infer(self._h, ids.ctypes.data, n, punc.ctypes.data,
+                                                     logits.ctypes.data if want_logits else None))
+        return (punc, logits) if want_logits else punc

@@ -27,15 +27,23 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kQW = 32;            // query rows per wave
 constexpr int kQB = 128;           // query rows per block
 constexpr int kKT = 32;            // keys per tile
-constexpr int kKS = kHeadDim + 4;  // padded K-tile row stride (floats): conflict-free ds_read_b128
-constexpr int kKVBuf = kKT * kKS + kKT * kHeadDim;  // floats per (K,V) buffer
-constexpr int kLdsFloats = (2 * kKVBuf > 4 * kQW * kKS) ? 2 * kKVBuf : 4 * kQW * kKS;
 
+// HD = head dimension: 128 (Paraformer SAN-M / cross-attention) or 32 (CT-Transformer, 256 / 8 heads)
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
     const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
     const int* __restrict__ q_off, const int* __restrict__ q_len, const int* __restrict__ kv_off,
     const int* __restrict__ kv_len, float scale) {
+  constexpr int kHeadDim = HD;
+  constexpr int kKS = HD + 4;                        // padded K-tile row stride: conflict-free ds_read_b128
+  constexpr int kKVBuf = kKT * kKS + kKT * HD;       // floats per (K,V) buffer
+  constexpr int kLdsFloats = (2 * kKVBuf > 4 * kQW * kKS) ? 2 * kKVBuf : 4 * kQW * kKS;
+  constexpr int NKB = HD / 8;                        // MFMA k-blocks of the QK^T product
+  constexpr int ND = HD / 32;                        // 32-wide d tiles of the output
+  constexpr int NP = HD / 32;                        // staging passes (256 threads move 1024 floats per pass)
+  constexpr int C4 = HD / 4;                         // float4 chunks per row
+  constexpr int RPP = 256 / C4;                      // rows per staging pass
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
   const int b = blockIdx.z, head = blockIdx.y;
@@ -48,45 +56,49 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   const int r = lane & 31, h = lane >> 5;
 
   // ---- Q slice of this lane: row q0 + wave*32 + r, d = 8*kb + 4*h + kk -------------------------
-  float4 qreg[16];
+  float4 qreg[NKB];
   {
     int qrow = q0 + wave * kQW + r;
     if (qrow >= Lq) qrow = Lq - 1;
     const float* qp = Q + (qbase + qrow) * ldq + head * kHeadDim + 4 * h;
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) qreg[kb] = *reinterpret_cast<const float4*>(qp + kb * 8);
+    for (int kb = 0; kb < NKB; ++kb) qreg[kb] = *reinterpret_cast<const float4*>(qp + kb * 8);
   }
 
   // ---- K/V tile staging (named registers + sched_barriers: hipcc otherwise spills the staging
   //      arrays to scratch and waits for the loads right where they are issued) -------------------------
-  const int lrow = tid >> 5, lc4 = tid & 31;   // 8 rows x 32 float4 per pass, 4 passes
+  const int lrow = tid / C4, lc4 = tid % C4;   // RPP rows x C4 float4 per pass, NP passes
   float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+  rk1 = rk2 = rk3 = rv1 = rv2 = rv3 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Kh = K + kbase * ldk + head * kHeadDim + 4 * lc4;
   const float* Vh = V + kbase * ldv + head * kHeadDim + 4 * lc4;
 #define PFHIP_KV_LOAD1(RK, RV, i, kt)                                                   \
   do {                                                                                  \
-    int key_ = (kt) * kKT + lrow + 8 * (i);                                             \
+    int key_ = (kt) * kKT + lrow + RPP * (i);                                           \
     key_ = key_ < Lk ? key_ : Lk - 1;                                                   \
     RK = *reinterpret_cast<const float4*>(Kh + (size_t)key_ * ldk);                     \
     RV = *reinterpret_cast<const float4*>(Vh + (size_t)key_ * ldv);                     \
   } while (0)
 #define PFHIP_KV_LOAD(kt)                                                               \
   do {                                                                                  \
-    PFHIP_KV_LOAD1(rk0, rv0, 0, kt); PFHIP_KV_LOAD1(rk1, rv1, 1, kt);                   \
-    PFHIP_KV_LOAD1(rk2, rv2, 2, kt); PFHIP_KV_LOAD1(rk3, rv3, 3, kt);                   \
+    PFHIP_KV_LOAD1(rk0, rv0, 0, kt);                                                    \
+    if (NP > 1) { PFHIP_KV_LOAD1(rk1, rv1, 1, kt); PFHIP_KV_LOAD1(rk2, rv2, 2, kt);     \
+                  PFHIP_KV_LOAD1(rk3, rv3, 3, kt); }                                    \
   } while (0)
 #define PFHIP_KV_STORE(buf)                                                             \
   do {                                                                                  \
     float* ks_ = lds + (buf) * kKVBuf + lrow * kKS + 4 * lc4;                           \
     float* vs_ = lds + (buf) * kKVBuf + kKT * kKS + lrow * kHeadDim + 4 * lc4;          \
     *reinterpret_cast<float4*>(ks_) = rk0;                                              \
-    *reinterpret_cast<float4*>(ks_ + 8 * kKS) = rk1;                                    \
-    *reinterpret_cast<float4*>(ks_ + 16 * kKS) = rk2;                                   \
-    *reinterpret_cast<float4*>(ks_ + 24 * kKS) = rk3;                                   \
     *reinterpret_cast<float4*>(vs_) = rv0;                                              \
-    *reinterpret_cast<float4*>(vs_ + 8 * kHeadDim) = rv1;                               \
-    *reinterpret_cast<float4*>(vs_ + 16 * kHeadDim) = rv2;                              \
-    *reinterpret_cast<float4*>(vs_ + 24 * kHeadDim) = rv3;                              \
+    if (NP > 1) {                                                                       \
+      *reinterpret_cast<float4*>(ks_ + 8 * kKS) = rk1;                                  \
+      *reinterpret_cast<float4*>(ks_ + 16 * kKS) = rk2;                                 \
+      *reinterpret_cast<float4*>(ks_ + 24 * kKS) = rk3;                                 \
+      *reinterpret_cast<float4*>(vs_ + 8 * kHeadDim) = rv1;                             \
+      *reinterpret_cast<float4*>(vs_ + 16 * kHeadDim) = rv2;                            \
+      *reinterpret_cast<float4*>(vs_ + 24 * kHeadDim) = rv3;                            \
+    }                                                                                   \
   } while (0)
 
   f32x16 oacc0, oacc1, oacc2, oacc3;
@@ -114,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     const float* kp = ks + r * kKS + 4 * h;
     float4 ka = *reinterpret_cast<const float4*>(kp);
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
-      const float4 kn = *reinterpret_cast<const float4*>(kp + (kb < 15 ? kb + 1 : kb) * 8);
+    for (int kb = 0; kb < NKB; ++kb) {
+      const float4 kn = *reinterpret_cast<const float4*>(kp + (kb < NKB - 1 ? kb + 1 : kb) * 8);
       __builtin_amdgcn_sched_barrier(0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qreg[kb].x, sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qreg[kb].y, sacc, 0, 0, 0);
@@ -150,23 +162,31 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     m_run = m_new;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { oacc0[e] *= alpha; oacc1[e] *= alpha; oacc2[e] *= alpha; oacc3[e] *= alpha; }
+      for (int e = 0; e < 16; ++e) {
+        oacc0[e] *= alpha;
+        if (ND > 1) { oacc1[e] *= alpha; oacc2[e] *= alpha; oacc3[e] *= alpha; }
+      }
     }
 
     // O^T[d][q] += sum_key V[key][d] * P^T[key][q]; V values of step e+1 are read under the 4 MFMAs of e
     const float* vp = vs + (4 * h) * kHeadDim + r;
-    float va0 = vp[0], va1 = vp[32], va2 = vp[64], va3 = vp[96];
+    float va0 = vp[0], va1 = 0.f, va2 = 0.f, va3 = 0.f;
+    if (ND > 1) { va1 = vp[32]; va2 = vp[64]; va3 = vp[96]; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int en = e < 15 ? e + 1 : e;
       const float* vrow = vp + ((en & 3) + 8 * (en >> 2)) * kHeadDim;
-      const float vn0 = vrow[0], vn1 = vrow[32], vn2 = vrow[64], vn3 = vrow[96];
+      const float vn0 = vrow[0];
+      float vn1 = 0.f, vn2 = 0.f, vn3 = 0.f;
+      if (ND > 1) { vn1 = vrow[32]; vn2 = vrow[64]; vn3 = vrow[96]; }
       __builtin_amdgcn_sched_barrier(0);
       const float pb = sacc[e];
       oacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, pb, oacc0, 0, 0, 0);
-      oacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, pb, oacc1, 0, 0, 0);
-      oacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(va2, pb, oacc2, 0, 0, 0);
-      oacc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(va3, pb, oacc3, 0, 0, 0);
+      if (ND > 1) {
+        oacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, pb, oacc1, 0, 0, 0);
+        oacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(va2, pb, oacc2, 0, 0, 0);
+        oacc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(va3, pb, oacc3, 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       va0 = vn0; va1 = vn1; va2 = vn2; va3 = vn3;
     }
@@ -189,17 +209,21 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     /* registers 4g..4g+3 are d = dt*32 + 8g + 4h + (0..3) of query column r */          \
     *reinterpret_cast<float4*>(os + r * kKS + (dt) * 32 + 8 * g + 4 * h) = o4;           \
   }
-  PFHIP_O_STORE(oacc0, 0) PFHIP_O_STORE(oacc1, 1) PFHIP_O_STORE(oacc2, 2) PFHIP_O_STORE(oacc3, 3)
+  PFHIP_O_STORE(oacc0, 0)
+  if (ND > 1) { PFHIP_O_STORE(oacc1, 1) PFHIP_O_STORE(oacc2, 2) PFHIP_O_STORE(oacc3, 3) }
 #undef PFHIP_O_STORE
   __syncthreads();
-  // each wave stores its own 32 x 128 tile: 2 rows per pass (32 lanes x float4 = one 512-B row)
+  // each wave stores its own 32 x HD tile as full rows: C4 lanes x float4 per row, 64/C4 rows per pass
+  {
+    constexpr int RW = 64 / C4;
 #pragma unroll
-  for (int pass = 0; pass < 16; ++pass) {
-    const int row = pass * 2 + h;
-    const int qrow = q0 + wave * kQW + row;
-    if (qrow < Lq) {
-      const float4 o4 = *reinterpret_cast<const float4*>(os + row * kKS + 4 * r);
-      *reinterpret_cast<float4*>(O + (qbase + qrow) * ldo + head * kHeadDim + 4 * r) = o4;
+    for (int pass = 0; pass < kQW / RW; ++pass) {
+      const int row = pass * RW + lane / C4, cc = lane % C4;
+      const int qrow = q0 + wave * kQW + row;
+      if (qrow < Lq) {
+        const float4 o4 = *reinterpret_cast<const float4*>(os + row * kKS + 4 * cc);
+        *reinterpret_cast<float4*>(O + (qbase + qrow) * ldo + head * kHeadDim + 4 * cc) = o4;
+      }
     }
   }
 }
@@ -209,10 +233,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 void launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                       float* O, int ldo, const int* q_off, const int* q_len, const int* kv_off,
                       const int* kv_len, int B, int H, int max_q_len, float scale, hipStream_t s) {
+  launch_attention_hd(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, kHeadDim, s);
+}
+
+void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                         int max_q_len, float scale, int head_dim, hipStream_t s) {
   if (B <= 0 || max_q_len <= 0) return;
   const dim3 grid((max_q_len + kQB - 1) / kQB, H, B), block(256);
-  hipLaunchKernelGGL(attention_kernel, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off,
-                     q_len, kv_off, kv_len, scale);
+  if (head_dim == 32)
+    hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
+                       kv_len, scale);
+  else
+    hipLaunchKernelGGL(attention_kernel<128>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
+                       kv_len, scale);
 }
 
 }  // namespace pfhip

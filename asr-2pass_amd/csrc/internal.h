@@ -67,6 +67,26 @@ pfhip_status build_frontend_tables(int n_mels, int sample_rate, FrontendTables* 
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// A linear layer repacked for the GEMM kernels: W zero-padded to [ceil(N/128)*128][ceil(K/32)*32], bias to the
+// padded N, so pad outputs are exact zeros (odd widths: FSMN-VAD 140/250/248, punctuation head 6).
+struct Lin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0, Np = 0, Kp = 0; };
+inline pfhip_status pack_linear(const float* w, const float* bias, int N, int K, Lin* out) {
+  out->N = N; out->K = K; out->Np = round_up(N, 128); out->Kp = round_up(K, 32);
+  std::vector<float> pw((size_t)out->Np * out->Kp, 0.f), pb((size_t)out->Np, 0.f);
+  for (int n = 0; n < N; ++n) std::memcpy(&pw[(size_t)n * out->Kp], w + (size_t)n * K, sizeof(float) * K);
+  if (bias) std::memcpy(pb.data(), bias, sizeof(float) * N);
+  HIP_TRY(hipMalloc((void**)&out->w, pw.size() * 4));
+  HIP_TRY(hipMemcpy(out->w, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&out->b, pb.size() * 4));
+  HIP_TRY(hipMemcpy(out->b, pb.data(), pb.size() * 4, hipMemcpyHostToDevice));
+  return PFHIP_OK;
+}
+inline void lin_gemm(hipStream_t s, const Lin& l, const float* A, int lda, float* C, int ldc, const float* R1, int ldr1,
+                     const float* R2, int ldr2, int M, bool relu) {
+  pfhip::launch_gemm_f32(A, lda, l.w, l.Kp, C, ldc, l.b, R1, ldr1, R2, ldr2, M, l.Np, l.Kp, relu, false, s);
+}
+inline void free_lin(Lin& l) { if (l.w) (void)hipFree(l.w); if (l.b) (void)hipFree(l.b); l.w = l.b = nullptr; }
+
 struct ProfRec { int cls; hipEvent_t e0, e1; };
 
 }  // namespace pfhip_detail

@@ -63,6 +63,11 @@ void launch_attention(const float* Q, int ldq, const float* K, int ldk, const fl
                       float* O, int ldo, const int* q_off, const int* q_len, const int* kv_off,
                       const int* kv_len, int B, int H, int max_q_len, float scale, hipStream_t s);
 
+// Same kernel with the head dimension chosen at run time: 128 or 32 (CT-Transformer: 256 / 8 heads).
+void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                         int max_q_len, float scale, int head_dim, hipStream_t s);
+
 // ---- predictor / CIF (SURVEY §8a rows a4,a12) -------------------------------------------------
 // col[row] = [h[t-1] | h[t] | h[t+1]] with zeros outside the utterance.  row_pos/row_len give the
 // local index and utterance length of every packed row.

@@ -35,6 +35,14 @@ int pfhip_op_attention(const float* Q, int ldq, const float* K, int ldk, const f
   pfhip::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, S(stream));
   return done();
 }
+int pfhip_op_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                          int max_q_len, float scale, int head_dim, void* stream) {
+  if (head_dim != 32 && head_dim != 128) return (int)hipErrorInvalidValue;
+  pfhip::launch_attention_hd(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, head_dim,
+                             S(stream));
+  return done();
+}
 int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
                  float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream) {
   if (D > 1024) return (int)hipErrorInvalidValue;

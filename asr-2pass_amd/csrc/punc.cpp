@@ -1,0 +1,200 @@
+// CT-Transformer punctuation forward on MI355X — the C ABI's pfhip_punc_* family.
+// Replaces the `m_session->Run` + Argmax loop of CTTransformer::Infer (onnxruntime/src/ct-transformer.cpp:162-204):
+// token ids [N] -> logits [N, 6] -> punctuation id = first maximum over the first CANDIDATE_NUM-1 classes.
+// Same kernels as the ASR encoder (fp32 MFMA GEMMs, FSMN memory block, fused attention instantiated for
+// d_k = 32) plus an embedding gather fused with the x*sqrt(d) + sinusoidal PE step.  The 272727 x 256
+// embedding table (279 MB) stays in HBM; a call touches N rows of it.
+#include <memory>
+
+#include "internal.h"
+#include "json_min.h"
+
+using namespace pfhip_detail;
+
+namespace pfhip {
+void launch_embed_gather(const int32_t* ids, const float* table, int vocab, int D, float* out, int ldo, int N,
+                         const float* inv_ts, float scale, hipStream_t s);   // punc.hip
+void launch_argmax_first(const float* logits, int ldl, int N, int ncls, int32_t* out, hipStream_t s);
+}
+
+struct pfhip_punc {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  int vocab = 0, d = 256, n_head = 8, ffn = 1024, layers = 4, n_punc = 6;
+  float* d_table = nullptr;
+  float* d_inv_ts = nullptr;
+  struct Layer { float *n1g, *n1b, *n2g, *n2b, *fsmn; Lin qkv, out, ffn1, ffn2; };
+  std::vector<Layer> L;
+  float *an_g = nullptr, *an_b = nullptr;
+  Lin head;
+  std::vector<float*> owned;
+  Buf ids, x, y, qkv, mem, ctx, h, logits, punc, meta;
+  int* h_pin = nullptr;
+};
+
+extern "C" {
+
+pfhip_status pfhip_punc_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
+                                           pfhip_punc** out) {
+  last_error().clear();
+  if (!blob || !manifest_json || !out) return fail(PFHIP_ERR_ARG, "null argument");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(PFHIP_ERR_ARG, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  pfhip::JValue man;
+  try { man = pfhip::JParser(manifest_json).parse(); }
+  catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
+  const pfhip::JValue* jc = man.get("config");
+  const pfhip::JValue* jt = man.get("tensors");
+  if (!jc || !jt || jt->kind != pfhip::JValue::OBJ) return fail(PFHIP_ERR_FORMAT, "manifest needs config and tensors");
+  std::unique_ptr<pfhip_punc> p(new pfhip_punc);
+  p->device = device;
+  p->vocab = (int)jc->number("vocab", 0);
+  p->d = (int)jc->number("d_model", 256);
+  p->n_head = (int)jc->number("n_head", 8);
+  p->ffn = (int)jc->number("ffn", 1024);
+  p->layers = (int)jc->number("layers", 4);
+  p->n_punc = (int)jc->number("n_punc", 6);
+  const int kernel = (int)jc->number("kernel", 11);
+  const int d = p->d;
+  if (p->vocab <= 0 || d % 128 || d > 512 || d / p->n_head != 32 || kernel != 11 || p->ffn % 128 || p->ffn > 2048 ||
+      p->n_punc < 2 || p->n_punc > 128)
+    return fail(PFHIP_ERR_UNSUPPORTED, "CT-Transformer kernels need d_model/n_head == 32, FSMN kernel 11");
+  const float* hb = static_cast<const float*>(blob);
+  auto get = [&](const std::string& name, std::vector<int> shape, const float** ptr) -> bool {
+    const pfhip::JValue* t = jt->get(name);
+    if (!t) { last_error() = "missing tensor " + name; return false; }
+    const pfhip::JValue* sh = t->get("shape");
+    const pfhip::JValue* of = t->get("offset");
+    if (!sh || !of || sh->arr.size() != shape.size()) { last_error() = "tensor " + name + " malformed"; return false; }
+    size_t n = 1;
+    for (size_t i = 0; i < shape.size(); ++i) {
+      if ((int)sh->arr[i].num != shape[i]) { last_error() = "tensor " + name + " has unexpected shape"; return false; }
+      n *= (size_t)shape[i];
+    }
+    const size_t off = (size_t)of->num;
+    if (off % 4 || off + n * 4 > blob_bytes) { last_error() = "tensor " + name + " out of blob"; return false; }
+    *ptr = hb + off / 4;
+    return true;
+  };
+  auto dev_copy = [&](const float* src, size_t n, float** dst) -> pfhip_status {
+    HIP_TRY(hipMalloc((void**)dst, n * 4));
+    HIP_TRY(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+    p->owned.push_back(*dst);
+    return PFHIP_OK;
+  };
+  auto vec = [&](const std::string& name, int n, float** dst) -> pfhip_status {
+    const float* src = nullptr;
+    if (!get(name, {n}, &src)) return PFHIP_ERR_FORMAT;
+    return dev_copy(src, n, dst);
+  };
+  auto lin = [&](const std::string& name, int N, int K, Lin* l) -> pfhip_status {
+    const float *w = nullptr, *b = nullptr;
+    if (!get(name + ".w", {N, K}, &w) || !get(name + ".b", {N}, &b)) return PFHIP_ERR_FORMAT;
+    return pack_linear(w, b, N, K, l);
+  };
+  pfhip_status st;
+  {
+    const float* tab = nullptr;
+    if (!get("embed.w", {p->vocab, d}, &tab)) return PFHIP_ERR_FORMAT;
+    if ((st = dev_copy(tab, (size_t)p->vocab * d, &p->d_table))) return st;
+  }
+  p->L.resize(p->layers);
+  for (int i = 0; i < p->layers; ++i) {
+    const std::string q = "enc." + std::to_string(i) + ".";
+    pfhip_punc::Layer& l = p->L[i];
+    const float* fw = nullptr;
+    if ((st = vec(q + "norm1.g", d, &l.n1g)) || (st = vec(q + "norm1.b", d, &l.n1b)) || (st = vec(q + "norm2.g", d, &l.n2g)) ||
+        (st = vec(q + "norm2.b", d, &l.n2b)) || (st = lin(q + "qkv", 3 * d, d, &l.qkv)) || (st = lin(q + "out", d, d, &l.out)) ||
+        (st = lin(q + "ffn1", p->ffn, d, &l.ffn1)) || (st = lin(q + "ffn2", d, p->ffn, &l.ffn2)))
+      return st;
+    if (!get(q + "fsmn.w", {d, kernel}, &fw)) return PFHIP_ERR_FORMAT;
+    if ((st = dev_copy(fw, (size_t)d * kernel, &l.fsmn))) return st;
+  }
+  if ((st = vec("enc.after_norm.g", d, &p->an_g)) || (st = vec("enc.after_norm.b", d, &p->an_b)) ||
+      (st = lin("out", p->n_punc, d, &p->head)))
+    return st;
+  {
+    const int half = d / 2;
+    std::vector<float> inv(half);
+    const float scale = (float)(-std::log(10000.0) / (half - 1));
+    for (int i = 0; i < half; ++i) inv[i] = (float)exp((double)(i * scale));
+    if ((st = dev_copy(inv.data(), half, &p->d_inv_ts))) return st;
+  }
+  HIP_TRY(p->meta.ensure(256));
+  HIP_TRY(hipHostMalloc((void**)&p->h_pin, 256, hipHostMallocDefault));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  *out = p.release();
+  return PFHIP_OK;
+}
+
+void pfhip_punc_destroy(pfhip_punc* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  (void)hipDeviceSynchronize();
+  for (Buf* b : {&p->ids, &p->x, &p->y, &p->qkv, &p->mem, &p->ctx, &p->h, &p->logits, &p->punc, &p->meta}) b->release();
+  for (auto& l : p->L) { free_lin(l.qkv); free_lin(l.out); free_lin(l.ffn1); free_lin(l.ffn2); }
+  free_lin(p->head);
+  for (float* q : p->owned) (void)hipFree(q);
+  if (p->h_pin) (void)hipHostFree(p->h_pin);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int pfhip_punc_num_classes(const pfhip_punc* p) { return p ? p->n_punc : 0; }
+
+pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, float* logits_out) {
+  last_error().clear();
+  if (!p || !ids || n <= 0 || !punc_out) return fail(PFHIP_ERR_ARG, "bad argument");
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= p->vocab) return fail(PFHIP_ERR_ARG, "token id outside the embedding table");
+  std::lock_guard<std::mutex> lk(p->mu);
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int d = p->d, Np = round_up(n, 128);
+  HIP_TRY(p->ids.ensure((size_t)n * 4));
+  HIP_TRY(p->x.ensure((size_t)Np * d * 4));
+  HIP_TRY(p->y.ensure((size_t)Np * d * 4));
+  HIP_TRY(p->qkv.ensure((size_t)Np * 3 * d * 4));
+  HIP_TRY(p->mem.ensure((size_t)Np * d * 4));
+  HIP_TRY(p->ctx.ensure((size_t)Np * d * 4));
+  HIP_TRY(p->h.ensure((size_t)Np * p->ffn * 4));
+  HIP_TRY(p->logits.ensure((size_t)Np * 128 * 4));
+  HIP_TRY(p->punc.ensure((size_t)n * 4));
+  HIP_TRY(hipMemcpyAsync(p->ids.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  p->h_pin[0] = 0; p->h_pin[1] = n;
+  HIP_TRY(hipMemcpyAsync(p->meta.p, p->h_pin, 8, hipMemcpyHostToDevice, s));
+  const int* d_off = p->meta.i();
+  const int* d_len = p->meta.i() + 1;
+  float* x = p->x.f();
+  pfhip::launch_embed_gather(static_cast<const int32_t*>(p->ids.p), p->d_table, p->vocab, d, x, d, n, p->d_inv_ts,
+                             sqrtf((float)d), s);
+  const float att_scale = 1.0f / sqrtf(32.f);
+  for (int i = 0; i < p->layers; ++i) {
+    const pfhip_punc::Layer& l = p->L[i];
+    pfhip::launch_layernorm(x, d, p->y.f(), d, l.n1g, l.n1b, n, d, d, 1e-12f, s);
+    lin_gemm(s, l.qkv, p->y.f(), d, p->qkv.f(), 3 * d, nullptr, 0, nullptr, 0, n, false);
+    pfhip::launch_fsmn(p->qkv.f() + 2 * d, 3 * d, l.fsmn, nullptr, 0, p->mem.f(), d, d_off, d_len, 1, n, d, s);
+    pfhip::launch_attention_hd(p->qkv.f(), 3 * d, p->qkv.f() + d, 3 * d, p->qkv.f() + 2 * d, 3 * d, p->ctx.f(), d, d_off,
+                               d_len, d_off, d_len, 1, p->n_head, n, att_scale, 32, s);
+    lin_gemm(s, l.out, p->ctx.f(), d, x, d, p->mem.f(), d, x, d, n, false);          // in_size == size: residual
+    pfhip::launch_layernorm(x, d, p->y.f(), d, l.n2g, l.n2b, n, d, d, 1e-12f, s);
+    lin_gemm(s, l.ffn1, p->y.f(), d, p->h.f(), p->ffn, nullptr, 0, nullptr, 0, n, true);
+    lin_gemm(s, l.ffn2, p->h.f(), p->ffn, x, d, x, d, nullptr, 0, n, false);
+  }
+  pfhip::launch_layernorm(x, d, p->y.f(), d, p->an_g, p->an_b, n, d, d, 1e-12f, s);
+  lin_gemm(s, p->head, p->y.f(), d, p->logits.f(), 128, nullptr, 0, nullptr, 0, n, false);
+  // Argmax(p, p + CANDIDATE_NUM - 1): first maximum over the first n_punc-1 classes (ct-transformer.cpp:193-196)
+  pfhip::launch_argmax_first(p->logits.f(), 128, n, p->n_punc - 1, static_cast<int32_t*>(p->punc.p), s);
+  HIP_TRY(hipMemcpyAsync(punc_out, p->punc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  if (logits_out)
+    HIP_TRY(hipMemcpy2DAsync(logits_out, (size_t)p->n_punc * 4, p->logits.p, 128 * 4, (size_t)p->n_punc * 4, n,
+                             hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return PFHIP_OK;
+}
+
+}  // extern "C"

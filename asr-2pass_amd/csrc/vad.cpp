@@ -12,10 +12,6 @@
 
 using namespace pfhip_detail;
 
-namespace {
-struct Lin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0, Np = 0, Kp = 0; };
-}
-
 struct pfhip_vad {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -33,20 +29,8 @@ struct pfhip_vad {
 
 namespace {
 
-pfhip_status pack_linear(const float* w, const float* bias, int N, int K, Lin* out) {
-  out->N = N; out->K = K; out->Np = round_up(N, 128); out->Kp = round_up(K, 32);
-  std::vector<float> pw((size_t)out->Np * out->Kp, 0.f), pb((size_t)out->Np, 0.f);
-  for (int n = 0; n < N; ++n) std::memcpy(&pw[(size_t)n * out->Kp], w + (size_t)n * K, sizeof(float) * K);
-  if (bias) std::memcpy(pb.data(), bias, sizeof(float) * N);
-  HIP_TRY(hipMalloc((void**)&out->w, pw.size() * 4));
-  HIP_TRY(hipMemcpy(out->w, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&out->b, pb.size() * 4));
-  HIP_TRY(hipMemcpy(out->b, pb.data(), pb.size() * 4, hipMemcpyHostToDevice));
-  return PFHIP_OK;
-}
-
 void lin_gemm(hipStream_t s, const Lin& l, const float* A, int lda, float* C, int ldc, int M, bool relu) {
-  pfhip::launch_gemm_f32(A, lda, l.w, l.Kp, C, ldc, l.b, nullptr, 0, nullptr, 0, M, l.Np, l.Kp, relu, false, s);
+  pfhip_detail::lin_gemm(s, l, A, lda, C, ldc, nullptr, 0, nullptr, 0, M, relu);
 }
 
 }  // namespace
@@ -142,7 +126,7 @@ void pfhip_vad_destroy(pfhip_vad* v) {
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
   for (Buf* b : {&v->pcm, &v->fb, &v->feats, &v->a, &v->b, &v->p, &v->f, &v->probs, &v->meta, &v->cache[0], &v->cache[1]}) b->release();
-  auto fl = [](Lin& l) { if (l.w) (void)hipFree(l.w); if (l.b) (void)hipFree(l.b); };
+  auto fl = [](Lin& l) { free_lin(l); };
   fl(v->in1); fl(v->in2); fl(v->out1); fl(v->out2);
   for (auto& l : v->blk_linear) fl(l);
   for (auto& l : v->blk_affine) fl(l);

@@ -24,6 +24,7 @@ def _lib():
         lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
         lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
+        lib.pfhip_op_attention_hd.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _ci, _vp]
         lib.pfhip_op_cif.argtypes = [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _cf, _cf, _vp, _vp, _vp, _vp]
         lib.pfhip_op_logsoftmax_argmax.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp]
         _bound = True
@@ -83,12 +84,12 @@ def fsmn(v, w, off, length, res=None):
     return out
 
 
-def attention(Q, K, V, q_off, q_len, kv_off, kv_len, n_head, scale):
-    O = torch.zeros((Q.shape[0], n_head * 128), dtype=torch.float32, device=Q.device)
+def attention(Q, K, V, q_off, q_len, kv_off, kv_len, n_head, scale, head_dim=128):
+    O = torch.zeros((Q.shape[0], n_head * head_dim), dtype=torch.float32, device=Q.device)
     B = q_off.numel()
-    _ck(_lib().pfhip_op_attention(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
-                                  _p(q_off), _p(q_len), _p(kv_off), _p(kv_len), B, n_head, int(q_len.max().item()),
-                                  scale, _stream()), "attention")
+    _ck(_lib().pfhip_op_attention_hd(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
+                                     _p(q_off), _p(q_len), _p(kv_off), _p(kv_len), B, n_head, int(q_len.max().item()),
+                                     scale, head_dim, _stream()), "attention")
     return O
 
 

@@ -177,3 +177,38 @@ def synth_generic(cfg, specs, seed):
 def synth_vad_weights(cfg=None, seed=4321):
     cfg = dict(FSMN_VAD) if cfg is None else cfg
     return synth_generic(cfg, vad_tensor_specs(cfg), seed)
+
+
+# ---- CT-Transformer punctuation (UPSTREAM: vocab 272727, 256-d SAN-M x4, 8 heads, FFN 1024) ----
+CT_TRANSFORMER = dict(model="ct_transformer", vocab=272727, d_model=256, n_head=8, ffn=1024, layers=4, kernel=11, n_punc=6)
+
+
+def punc_tensor_specs(cfg):
+    d, f, k = cfg["d_model"], cfg["ffn"], cfg["kernel"]
+    specs = [("embed.w", [cfg["vocab"], d], ("normal", 1.0))]
+
+    def lin(name, out_f, in_f):
+        specs.append((name + ".w", [out_f, in_f], ("normal", 1.0 / math.sqrt(in_f))))
+        specs.append((name + ".b", [out_f], ("normal", 0.02)))
+
+    def ln(name, n):
+        specs.append((name + ".g", [n], ("const", 1.0)))
+        specs.append((name + ".b", [n], ("const", 0.0)))
+
+    for i in range(cfg["layers"]):
+        p = f"enc.{i}."
+        ln(p + "norm1", d)
+        lin(p + "qkv", 3 * d, d)
+        specs.append((p + "fsmn.w", [d, k], ("normal", 1.0 / math.sqrt(k))))
+        lin(p + "out", d, d)
+        ln(p + "norm2", d)
+        lin(p + "ffn1", f, d)
+        lin(p + "ffn2", d, f)
+    ln("enc.after_norm", d)
+    lin("out", cfg["n_punc"], d)
+    return specs
+
+
+def synth_punc_weights(cfg=None, seed=2468):
+    cfg = dict(CT_TRANSFORMER) if cfg is None else cfg
+    return synth_generic(cfg, punc_tensor_specs(cfg), seed)

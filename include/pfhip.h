@@ -138,6 +138,19 @@ int pfhip_vad_num_classes(const pfhip_vad* v);
 pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
                                size_t cap_floats, int* n_frames);
 
+/* ---- CT-Transformer punctuation forward ------------------------------------------------------------
+ *   pfhip_punc_create_from_memory <-> CTTransformer::InitPunc session load (ct-transformer.cpp:14-37)
+ *   pfhip_punc_infer              <-> CTTransformer::Infer (ct-transformer.cpp:162-204): ids [n] -> punctuation id
+ *                                     per token = first maximum over the first CANDIDATE_NUM-1 classes; logits_out
+ *                                     (optional) gets the [n, n_classes] scores.  Tokenisation and the 20-token
+ *                                     mini-sentence bookkeeping of AddPunc (:39-155) stay on the host above this. */
+typedef struct pfhip_punc pfhip_punc;
+pfhip_status pfhip_punc_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
+                                           pfhip_punc** out);
+void pfhip_punc_destroy(pfhip_punc* p);
+int pfhip_punc_num_classes(const pfhip_punc* p);
+pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, float* logits_out);
+
 /* ---- inspection (parity tests) -----------------------------------------------------------------
  * Copies a named intermediate of the LAST forward to host: "feats" [M,560], "enc" [M,d],
  * "alphas" [M] (without the tail slot), "emb" [sum fires, d], "logp" [sum fires, vocab].

@@ -27,6 +27,10 @@ int pfhip_op_fsmn(const float* v, int ldv, const float* w, const float* res, int
 int pfhip_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                        const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                        int max_q_len, float scale, void* stream);
+/* Same, head dimension 32 or 128 chosen at run time (CT-Transformer: 256 / 8 heads). */
+int pfhip_op_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                          int max_q_len, float scale, int head_dim, void* stream);
 /* CIF integrate-and-fire (onnxruntime/src/paraformer-online.cpp:301-327) + tail slot. */
 int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
                  float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream);

@@ -1,0 +1,58 @@
+"""GPU: CT-Transformer forward (pfhip_punc_*) against the oracle, incl. the 5-of-6 argmax quirk
+(ct-transformer.cpp:193-196) and the d_k = 32 instantiation of the attention kernel."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import ct_transformer as C
+from oracle import paraformer as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def punc(pkg, weights_mod):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    cfg = dict(weights_mod.CT_TRANSFORMER, vocab=5000)          # small table; same widths as the real model
+    man, blob = weights_mod.synth_punc_weights(cfg)
+    h = pkg.CTTransformerHip().InitPunc((man, blob))
+    yield h, P.Weights(man, blob)
+    h.close()
+
+
+@pytest.mark.parametrize("n", [1, 20, 33, 64, 65, 220])
+def test_infer_matches_oracle(punc, n):
+    h, W = punc
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, 5000, n).astype(np.int32)
+    got_p, got_l = h.Infer(ids, want_logits=True)
+    ref_l, ref_p = C.infer(ids, W)
+    assert np.abs(got_l - ref_l).max() < 1e-3
+    assert np.array_equal(got_p, ref_p)
+    assert got_p.max() <= 4            # class 5 can never be chosen: Argmax over CANDIDATE_NUM-1 classes
+
+
+def test_bad_token_id_is_an_error(punc, pkg):
+    h, _ = punc
+    with pytest.raises(pkg.PfhipError):
+        h.Infer(np.asarray([1, 2, 999999], np.int32))
+
+
+def test_attention_head_dim_32_op(pkg):
+    ops = importlib.import_module("asr_2pass_amd.ops")
+    rng = np.random.default_rng(5)
+    H, dk = 8, 32
+    lens = [1, 33, 100]
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    Q = rng.standard_normal((sum(lens), H * dk)).astype(np.float32)
+    K = rng.standard_normal((sum(lens), H * dk)).astype(np.float32)
+    V = rng.standard_normal((sum(lens), H * dk)).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ln = dev(np.asarray(lens, np.int32))
+    O = ops.attention(dev(Q), dev(K), dev(V), dev(off), ln, dev(off), ln, H, dk ** -0.5, head_dim=32).cpu().numpy()
+    for b, (o, L) in enumerate(zip(off, lens)):
+        ref = P.mha(Q[o:o + L].astype(np.float64), K[o:o + L].astype(np.float64), V[o:o + L].astype(np.float64), H)
+        assert np.abs(O[o:o + L] - ref).max() < 2e-5

@@ -283,7 +283,8 @@ class ParaformerHip:
         return dict(token_num=tn, n_fires=nf, n_frames=fr, ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)])
 
     def profile_enable(self, on=True):
-        _check(self._lib, self._lib.pfhip_profile_enable(self._h, 1 if on else 0))
+        """on: False/0 off, True/1 every kernel class, other int = bit mask of classes (see pfhip.h)."""
+        _check(self._lib, self._lib.pfhip_profile_enable(self._h, int(on)))
 
     def profile_read(self, reset=True):
         p = _Profile()

@@ -130,7 +130,7 @@ struct pfhip_model {
   int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr;
 
   // profiling
-  bool prof_on = false;
+  int prof_mask = 0;             // bit c set -> launches of kernel class c are bracketed by events
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -147,7 +147,7 @@ using pfhip::launch_gemm_f32;
 struct Scope {
   pfhip_model* m; hipStream_t s; int cls; hipEvent_t e1 = nullptr;
   Scope(pfhip_model* m_, hipStream_t s_, int cls_, double flops, double bytes) : m(m_), s(s_), cls(cls_) {
-    if (!m->prof_on) return;
+    if (!((m->prof_mask >> cls) & 1)) return;
     if (m->ev_used + 2 > m->ev_pool.size()) {
       for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; m->ev_pool.push_back(e); }
     }

@@ -685,7 +685,7 @@ pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size
 pfhip_status pfhip_profile_enable(pfhip_model* m, int on) {
   if (!m) return fail(PFHIP_ERR_ARG, "null model");
   std::lock_guard<std::mutex> lk(m->mu);
-  m->prof_on = on != 0;
+  m->prof_mask = on < 0 ? 0 : (on == 1 ? 0xff : on);   // 0 off, 1 all classes, else a bit mask of classes << 0
   return PFHIP_OK;
 }
 

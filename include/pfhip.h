@@ -160,6 +160,8 @@ pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size
 
 /* ---- per-kernel timing (bench.py roofline leg) -------------------------------------------------
  * When enabled, each launch of a kernel class is bracketed by hipEvents on the launch stream.
+ * `on`: 0 = off, 1 = every class, any other value = bit mask of classes (bit c = class c; bench.py times only
+ * the dominant class, 1<<0 | 1<<8 ... see below, so that the event records do not perturb the timed region).
  * Classes: 0 gemm, 1 attention, 2 layernorm, 3 fsmn, 4 fbank, 5 cif, 6 head(log-softmax/argmax), 7 other. */
 #define PFHIP_NUM_KCLASS 8
 typedef struct {

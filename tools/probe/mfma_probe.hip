@@ -81,6 +81,73 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ A, con
 }
 
 
+// ---- V36: prefetch distance 2 (two staging register sets), early LDS store ----
+__global__ __launch_bounds__(256, 2) void probe_pf2(const float* __restrict__ A, const float* __restrict__ W, float* C, const float* R,
+                                                    int lda, int ldw, int ldc, int nk, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStage];
+  float* const As = lds; float* const Bs = lds + 2 * kStage;
+  const int bid = blockIdx.x;
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int lrow = tid >> 3, lc4 = tid & 7;
+  const float* Ag = A + (size_t)(m0 + lrow) * lda + 4 * lc4;
+  const float* Wg = W + (size_t)(n0 + lrow) * ldw + 4 * lc4;
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+#define GLOADS(k0) do { sa0 = *(const float4*)(Ag + (k0)); sa1 = *(const float4*)(Ag + (size_t)32 * lda + (k0)); \
+  sa2 = *(const float4*)(Ag + (size_t)64 * lda + (k0)); sa3 = *(const float4*)(Ag + (size_t)96 * lda + (k0)); \
+  sb0 = *(const float4*)(Wg + (k0)); sb1 = *(const float4*)(Wg + (size_t)32 * ldw + (k0)); \
+  sb2 = *(const float4*)(Wg + (size_t)64 * ldw + (k0)); sb3 = *(const float4*)(Wg + (size_t)96 * ldw + (k0)); } while (0)
+#define SSTORES(buf) do { float* as_ = As + (buf) * kStage + lrow * kLds + 4 * lc4; float* bs_ = Bs + (buf) * kStage + lrow * kLds + 4 * lc4; \
+  *(float4*)(as_) = sa0; *(float4*)(as_ + 32 * kLds) = sa1; *(float4*)(as_ + 64 * kLds) = sa2; *(float4*)(as_ + 96 * kLds) = sa3; \
+  *(float4*)(bs_) = sb0; *(float4*)(bs_ + 32 * kLds) = sb1; *(float4*)(bs_ + 64 * kLds) = sb2; *(float4*)(bs_ + 96 * kLds) = sb3; } while (0)
+  f32x16 acc00, acc01, acc10, acc11;
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+  GLOAD(0); SSTORE(0);
+  GLOAD(32 < nk * 32 ? 32 : 0);            // tile 1 in set R
+  __syncthreads();
+  const int a_off = (wr * 64 + r) * kLds + 4 * h, b_off = (wc * 64 + r) * kLds + 4 * h;
+  float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
+  FRAG(fa0, fa1, fb0, fb1, 0, 0);
+  // iteration kt computes tile kt from buffer kt&1; tile kt+1 is in registers (set R if kt even, S if odd);
+  // tile kt+2 is loaded into the other set at the top.
+  for (int kt = 0; kt < nk; kt += 2) {
+    { const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * 32;
+      GLOADS(k2); SB;
+      FRAG(ga0, ga1, gb0, gb1, 0, 1); SB; M16(fa0, fa1, fb0, fb1) SB;
+      FRAG(fa0, fa1, fb0, fb1, 0, 2); SB; M16(ga0, ga1, gb0, gb1) SB;
+      FRAG(ga0, ga1, gb0, gb1, 0, 3); SB; SSTORE(1); SB; M16(fa0, fa1, fb0, fb1) SB;
+      __syncthreads();
+      FRAG(fa0, fa1, fb0, fb1, 1, 0); SB; M16(ga0, ga1, gb0, gb1) SB; }
+    { const int k3 = (kt + 3 < nk ? kt + 3 : nk - 1) * 32;
+      GLOAD(k3); SB;
+      FRAG(ga0, ga1, gb0, gb1, 1, 1); SB; M16(fa0, fa1, fb0, fb1) SB;
+      FRAG(fa0, fa1, fb0, fb1, 1, 2); SB; M16(ga0, ga1, gb0, gb1) SB;
+      FRAG(ga0, ga1, gb0, gb1, 1, 3); SB; SSTORES(0); SB; M16(fa0, fa1, fb0, fb1) SB;
+      __syncthreads();
+      FRAG(fa0, fa1, fb0, fb1, 0, 0); SB; M16(ga0, ga1, gb0, gb1) SB; }
+  }
+  __syncthreads();
+  float* const Cs = lds; constexpr int kCs = 132;
+  { float* cw = Cs + (wr * 64 + 4 * h) * kCs + wc * 64 + r;
+    for (int e = 0; e < 16; ++e) { const int ro = ((e & 3) + 8 * (e >> 2)) * kCs; cw[ro] = acc00[e]; cw[ro + 32] = acc01[e]; cw[ro + 32 * kCs] = acc10[e]; cw[ro + 32 * kCs + 32] = acc11[e]; } }
+  __syncthreads();
+  const int c4 = tid & 31, rsub = tid >> 5;
+  for (int pass = 0; pass < 16; ++pass) { const int row = pass * 8 + rsub;
+    *(float4*)(C + (size_t)(m0 + row) * ldc + n0 + 4 * c4) = *(const float4*)(Cs + row * kCs + 4 * c4); }
+}
+float run_pf2(const float* A, const float* W, float* C, const float* R, int M, int N, int K, int iters) {
+  const int tiles_n = N / 128, blocks = (M / 128) * tiles_n;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(probe_pf2, dim3(blocks), dim3(256), 0, 0, A, W, C, R, K, K, N, K / 32, tiles_n);
+  hipEventRecord(e0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(probe_pf2, dim3(blocks), dim3(256), 0, 0, A, W, C, R, K, K, N, K / 32, tiles_n);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / iters;
+}
+
 // ---- V40: LDS-DMA staging (global_load_lds_dwordx4), unpadded 128-B rows, source-side XOR swizzle ----
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -185,6 +252,11 @@ int main() {
       float c = run<32>(A, W, C, R, M, N, K, 20); printf("V32 early sstore  %7.1f us %6.1f TF\n", c * 1e3, fl / c / 1e9);
       float d3 = run<33>(A, W, C, R, M, N, K, 20), d4 = run<34>(A, W, C, R, M, N, K, 20), d5 = run<35>(A, W, C, R, M, N, K, 20);
       printf("V33 +sleep32      %7.1f us %6.1f TF\nV34 +sleep64      %7.1f us %6.1f TF\nV35 +sleep128     %7.1f us %6.1f TF\n", d3 * 1e3, fl / d3 / 1e9, d4 * 1e3, fl / d4 / 1e9, d5 * 1e3, fl / d5 / 1e9); }
+    { float d = run_pf2(A, W, C, R, M, N, K, 20); printf("V36 prefetch dist 2 %7.1f us %6.1f TF\n", d * 1e3, fl / d / 1e9);
+      std::vector<float> c1((size_t)128 * N), c2((size_t)128 * N);
+      run<4>(A, W, C, R, M, N, K, 1); hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+      run_pf2(A, W, C, R, M, N, K, 1); hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost);
+      double md = 0; for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i])); printf("    V36 vs V4 max diff %g\n", md); }
     { float d = run_dma(A, W, C, R, M, N, K, 20); printf("V40 LDS-DMA full   %7.1f us %6.1f TF\n", d * 1e3, fl / d / 1e9);
       std::vector<float> c1((size_t)128 * N), c2((size_t)128 * N);
       run<4>(A, W, C, R, M, N, K, 1); hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);

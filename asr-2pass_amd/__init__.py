@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
+    "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
 ]
 
@@ -95,6 +96,12 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_vad_reset.argtypes = [vp]
     lib.pfhip_vad_num_classes.argtypes = [vp]
     lib.pfhip_vad_forward.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci)]
+    lib.pfhip_vad_forward_sil.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci)]
+    lib.pfhip_vadseg_create.argtypes = [ctypes.POINTER(vp)]
+    lib.pfhip_vadseg_destroy.argtypes = [vp]
+    lib.pfhip_vadseg_destroy.restype = None
+    lib.pfhip_vadseg_reset.argtypes = [vp]
+    lib.pfhip_vadseg_feed.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ctypes.c_float, ci, vp, ci, ctypes.POINTER(ci)]
     lib.pfhip_punc_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
     lib.pfhip_punc_destroy.argtypes = [vp]
     lib.pfhip_punc_destroy.restype = None
@@ -368,6 +375,16 @@ class FsmnVadHip:
     def InitCache(self):
         _check(self._lib, self._lib.pfhip_vad_reset(self._h))
 
+    def ForwardSil(self, waves, is_final=False):
+        """Frame-wise silence posterior only (what E2EVadModel reads)."""
+        x = np.ascontiguousarray(waves, dtype=np.float32)
+        cap = max(0, (x.size - 400) // 160 + 1) + 1
+        sil = np.zeros(cap, np.float32)
+        n = ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_vad_forward_sil(self._h, x.ctypes.data if x.size else None, int(x.size),
+                                                          1 if is_final else 0, sil.ctypes.data, cap, ctypes.byref(n)))
+        return sil[:n.value]
+
     def Forward(self, waves, is_final=False):
         x = np.ascontiguousarray(waves, dtype=np.float32)
         C = self._lib.pfhip_vad_num_classes(self._h)
@@ -415,3 +432,39 @@ class CTTransformerHip:
         _check(self._lib, self._lib.pfhip_punc_infer(self._h, ids.ctypes.data, n, punc.ctypes.data,
                                                      logits.ctypes.data if want_logits else None))
         return (punc, logits) if want_logits else punc
+
+
+class E2EVadModelHost:
+    """ctypes handle on the host-side end-point detector (csrc/host/vad_segmenter.cpp), call-compatible with
+    `funasr::E2EVadModel::operator()` (onnxruntime/src/e2e-vad.h:303-362) except that it takes the class-0 score
+    column instead of the whole score matrix."""
+
+    def __init__(self):
+        self._lib = load_lib()
+        self._h = ctypes.c_void_p()
+        _check(self._lib, self._lib.pfhip_vadseg_create(ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.pfhip_vadseg_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, score_sil, waveform, is_final=False, online=False, max_end_sil=800, max_single_segment_time=15000,
+                 speech_noise_thres=0.8, sample_rate=16000):
+        sc = np.ascontiguousarray(score_sil, dtype=np.float32)
+        wv = np.ascontiguousarray(waveform, dtype=np.float32)
+        cap = sc.size + 8
+        segs = np.zeros((cap, 2), np.int32)
+        n = ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_vadseg_feed(self._h, sc.ctypes.data if sc.size else None, int(sc.size),
+                                                      wv.ctypes.data if wv.size else None, int(wv.size), int(is_final),
+                                                      int(online), int(max_end_sil), int(max_single_segment_time),
+                                                      float(speech_noise_thres), int(sample_rate), segs.ctypes.data, cap,
+                                                      ctypes.byref(n)))
+        return [[int(a), int(b)] for a, b in segs[:n.value]]

@@ -151,8 +151,21 @@ pfhip_status pfhip_vad_reset(pfhip_vad* v) {
 
 int pfhip_vad_num_classes(const pfhip_vad* v) { return v ? v->n_out : 0; }
 
+static pfhip_status vad_forward_impl(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
+                                     size_t cap_floats, int* n_frames, bool sil_only);
+
 pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
                                size_t cap_floats, int* n_frames) {
+  return vad_forward_impl(v, pcm, n_samples, is_final, probs, cap_floats, n_frames, false);
+}
+
+pfhip_status pfhip_vad_forward_sil(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* sil_prob,
+                                   size_t cap_floats, int* n_frames) {
+  return vad_forward_impl(v, pcm, n_samples, is_final, sil_prob, cap_floats, n_frames, true);
+}
+
+static pfhip_status vad_forward_impl(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
+                                     size_t cap_floats, int* n_frames, bool sil_only) {
   last_error().clear();
   if (!v || n_samples < 0 || (n_samples > 0 && !pcm) || !n_frames) return fail(PFHIP_ERR_ARG, "bad argument");
   std::lock_guard<std::mutex> lk(v->mu);
@@ -162,7 +175,7 @@ pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, in
   const int T = (F + v->lfr_n - 1) / v->lfr_n;               // fsmn-vad.cpp:202
   *n_frames = T;
   if (T == 0) return PFHIP_OK;                                // fsmn-vad.cpp:245-247
-  if ((size_t)T * v->n_out > cap_floats && probs) return fail(PFHIP_ERR_CAPACITY, "probs buffer too small");
+  if ((size_t)T * (sil_only ? 1 : v->n_out) > cap_floats && probs) return fail(PFHIP_ERR_CAPACITY, "probs buffer too small");
   const int Tp = round_up(T, 128);
   HIP_TRY(v->pcm.ensure((size_t)n_samples * 4));
   HIP_TRY(v->fb.ensure((size_t)F * 80 * 4));
@@ -200,7 +213,9 @@ pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, in
   lin_gemm(s, v->out2, v->a.f(), 256, v->b.f(), 256, T, false);
   pfhip::launch_softmax_rows(v->b.f(), 256, T, v->n_out, v->probs.f(), s);
   if (!is_final) v->cache_cur ^= 1;                             // fsmn-vad.cpp:129-134: caches kept only if not final
-  if (probs) HIP_TRY(hipMemcpyAsync(probs, v->probs.p, (size_t)T * v->n_out * 4, hipMemcpyDeviceToHost, s));
+  if (probs && !sil_only) HIP_TRY(hipMemcpyAsync(probs, v->probs.p, (size_t)T * v->n_out * 4, hipMemcpyDeviceToHost, s));
+  if (probs && sil_only)        // column 0 of the [T, n_out] score matrix
+    HIP_TRY(hipMemcpy2DAsync(probs, 4, v->probs.p, (size_t)v->n_out * 4, 4, T, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   return PFHIP_OK;

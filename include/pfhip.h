@@ -138,6 +138,26 @@ int pfhip_vad_num_classes(const pfhip_vad* v);
 pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* probs,
                                size_t cap_floats, int* n_frames);
 
+/* Same forward, but only the silence posterior (class 0) of each frame comes back — the one column the end-point
+ * detector reads (e2e-vad.h:103,607-609): T floats instead of T x 248. */
+pfhip_status pfhip_vad_forward_sil(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* sil_prob,
+                                   size_t cap_floats, int* n_frames);
+
+/* ---- VAD end-point detector (host logic) -----------------------------------------------------------
+ * `funasr::E2EVadModel` (onnxruntime/src/e2e-vad.h:268-783, WindowDetector :181-266, VADXOptions defaults :78-107)
+ * restated on the host: sequential threshold / window logic over ~100 frames per second, no device work.
+ *   pfhip_vadseg_feed <-> E2EVadModel::operator()(score, waveform, is_final, online, max_end_sil,
+ *                         max_single_segment_time, speech_noise_thres, sample_rate) (:303-362); segments are written as
+ *                         (start_ms, end_ms) pairs, -1 = "open" in online mode.  *n_segments > cap_pairs -> PFHIP_ERR_CAPACITY. */
+typedef struct pfhip_vadseg pfhip_vadseg;
+pfhip_status pfhip_vadseg_create(pfhip_vadseg** out);
+void pfhip_vadseg_destroy(pfhip_vadseg* s);
+pfhip_status pfhip_vadseg_reset(pfhip_vadseg* s);
+pfhip_status pfhip_vadseg_feed(pfhip_vadseg* s, const float* sil_prob, int n_frames, const float* waveform,
+                               int n_samples, int is_final, int online, int max_end_sil, int max_single_segment_time,
+                               float speech_noise_thres, int sample_rate, int32_t* segments, int cap_pairs,
+                               int* n_segments);
+
 /* ---- CT-Transformer punctuation forward ------------------------------------------------------------
  *   pfhip_punc_create_from_memory <-> CTTransformer::InitPunc session load (ct-transformer.cpp:14-37)
  *   pfhip_punc_infer              <-> CTTransformer::Infer (ct-transformer.cpp:162-204): ids [n] -> punctuation id

@@ -1,0 +1,88 @@
+"""GPU: the long-audio flow (VAD forward -> end-point detector -> length-sorted dynamic batches -> batched
+Paraformer forward -> re-ordering; funasrruntime.cpp:208-337) against the same flow built from the oracles."""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import synth_pcm
+from oracle import e2e_vad as E
+from oracle import fsmn_vad as V
+from oracle import paraformer as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make_file(rng):
+    """~45 s: speech-like bursts separated by 1.2-s digital silence."""
+    parts = []
+    for i, sec in enumerate([4.0, 7.5, 2.2, 11.0, 5.3]):
+        parts.append(synth_pcm(i, int(sec * 16000), rng))
+        parts.append(np.zeros(int(1.2 * 16000), np.float32))
+    return np.concatenate(parts)
+
+
+def shape_vad_weights(man, blob):
+    """Synthetic VAD weights do not separate speech from silence; make class 0 follow the frame energy so that the
+    detector sees real segments: out2 bias favours silence, and the input layers pass log-mel energy through."""
+    W = P.Weights(man, blob)
+    for k in list(W.t):
+        if k.endswith(".w") and not k.startswith("cmvn"):
+            W.t[k][...] = 0
+        if k.endswith(".b") and not k.startswith("cmvn"):
+            W.t[k][...] = 0
+    # energy path: mean log-mel of the centre frame -> unit 0 of every layer -> logit of class 0 (negative slope)
+    W["in1.w"][0, 160:240] = 1.0 / 80
+    W["in2.w"][0, 0] = 1.0
+    for i in range(man["config"]["layers"]):
+        W[f"blk.{i}.linear.w"][0, 0] = 1.0
+        W[f"blk.{i}.affine.w"][0, 0] = 1.0
+    W["out1.w"][0, 0] = 1.0
+    W["out2.w"][0, 0] = -4.0
+    W["out2.b"][0] = 8.0          # energy ~ (x - 8) * 0.3 after CMVN: silence (log eps) strongly negative -> relu 0
+    return man, blob
+
+
+def test_long_audio_flow_matches_oracle_flow(pkg, weights_mod):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    pipeline = importlib.import_module("asr_2pass_amd.pipeline")
+    rng = np.random.default_rng(9)
+    pcm = make_file(rng)
+    vman, vblob = shape_vad_weights(*weights_mod.synth_vad_weights())
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=1, vocab=300)
+    aman, ablob = weights_mod.synth_weights(cfg)
+    vad = pkg.FsmnVadHip().InitVad((vman, vblob))
+    asr = pkg.ParaformerHip().InitAsr((aman, ablob))
+    seg = pkg.E2EVadModelHost()
+    ids, frames = pipeline.infer_buffer(pcm, asr, vad, seg, batch_size=4, vad_max_len=60000)
+    # ---- oracle flow: 1-s slices through the oracle VAD + online detector, like Audio::CutSplit does ----
+    VW, AW = P.Weights(vman, vblob), P.Weights(aman, ablob)
+    sil_ref = V.FsmnVad(VW).Forward(pcm, True)[:, 0]
+    sil_got = vad.ForwardSil(pcm, is_final=True)
+    assert np.abs(sil_ref - sil_got).max() < 2e-5
+    ref_segs = E.E2EVadModel()(sil_ref, pcm[:400 + 160 * (len(sil_ref) - 1)], True, False, 800, 60000, 0.9)
+    assert [(s * 16, min(e * 16, len(pcm))) for s, e in ref_segs] == frames
+    assert len(frames) == 5                                  # five bursts -> five segments
+    for (s, e), got in zip(frames, ids):
+        ref = P.forward_pcm(pcm[s:e], AW)
+        assert list(got) == list(ref["ids"])
+    vad.close(); asr.close(); seg.close()
+
+
+def test_fetch_dynamic_rule(pkg):
+    pipeline = importlib.import_module("asr_2pass_amd.pipeline")
+    S = 16000
+    # sorted ascending (CutSplit): 8 x 20 s, then one 70-s segment (>= max_sent)
+    q = [(0, 20 * S)] * 8 + [(0, 70 * S)]
+    b1 = pipeline.fetch_dynamic(q, 32)
+    assert len(b1) == 8                       # 9th would be >= 60 s -> own batch
+    b2 = pipeline.fetch_dynamic(q, 32)
+    assert len(b2) == 1 and b2[0][1] == 70 * S and q == []
+    # max_acc: max_len * count <= 300 s
+    q = [(0, 50 * S)] * 10
+    assert len(pipeline.fetch_dynamic(q, 32)) == 6
+    # batch_size cap
+    q = [(0, S)] * 10
+    assert len(pipeline.fetch_dynamic(q, 4)) == 4

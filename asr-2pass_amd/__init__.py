@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
+    "pfhip_is_contextual", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
@@ -83,6 +84,9 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_offline_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
     lib.pfhip_extract_feats.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ctypes.c_size_t, vp]
     lib.pfhip_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.pfhip_is_contextual.argtypes = [vp]
+    lib.pfhip_hotword_embed.argtypes = [vp, vp, vp, ci, vp]
+    lib.pfhip_set_hotwords.argtypes = [vp, vp, ci]
     lib.pfhip_stream_create.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(vp)]
     lib.pfhip_stream_destroy.argtypes = [vp]
     lib.pfhip_stream_destroy.restype = None
@@ -198,7 +202,30 @@ class ParaformerHip:
         return self._lib.pfhip_vocab_size(self._h)
 
     # -- the hot path --------------------------------------------------------------------------------
-    def forward_ids(self, din: Sequence[np.ndarray], want_logp=False, max_tokens=None):
+    def CompileHotwordEmbedding(self, hotword_ids: Sequence[Sequence[int]]):
+        """Paraformer::CompileHotwordEmbedding from the id stage on (paraformer.cpp:629-693): each hotword's token ids are
+        truncated / zero-padded to 10, the blank row [1,0,...] is appended, the embedder runs on the GPU and row len-1
+        is taken.  (Hotword string -> token ids is host text handling, :601-628.)  Returns [H+1, d] float32; a plain
+        model returns one zero row (:594-599)."""
+        d = self._lib.pfhip_d_model(self._h)
+        if not self._lib.pfhip_is_contextual(self._h):
+            return np.zeros((1, d), np.float32)
+        rows, lens = [], []
+        for ids in hotword_ids:
+            ids = list(ids)[:10]
+            if not ids:
+                continue
+            rows.append(ids + [0] * (10 - len(ids)))
+            lens.append(len(ids))
+        rows.append([1] + [0] * 9)
+        lens.append(1)
+        mat = np.ascontiguousarray(rows, np.int32)
+        ln = np.ascontiguousarray(lens, np.int32)
+        out = np.zeros((len(rows), d), np.float32)
+        _check(self._lib, self._lib.pfhip_hotword_embed(self._h, mat.ctypes.data, ln.ctypes.data, len(rows), out.ctypes.data))
+        return out
+
+    def forward_ids(self, din: Sequence[np.ndarray], want_logp=False, max_tokens=None, hw_emb=None):
         """Batched forward.  Returns dict(token_num, n_fires, n_frames, ids=list of int arrays,
         logp=list of [n_fires, V] arrays or None)."""
         B = len(din)
@@ -222,7 +249,9 @@ class ParaformerHip:
         out.n_frames = fr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
         out.logp = logp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_logp else None
         out.max_tokens = max_tokens
-        _check(self._lib, self._lib.pfhip_offline_forward(self._h, ptrs, lens, B, None, 0, ctypes.byref(out)))
+        hw = np.ascontiguousarray(hw_emb, dtype=np.float32) if hw_emb is not None else None
+        _check(self._lib, self._lib.pfhip_offline_forward(self._h, ptrs, lens, B, hw.ctypes.data if hw is not None else None,
+                                                          int(hw.shape[0]) if hw is not None else 0, ctypes.byref(out)))
         return dict(token_num=tn, n_fires=nf, n_frames=fr,
                     ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)],
                     logp=[logp[b, :nf[b]].copy() for b in range(B)] if want_logp else None)
@@ -233,7 +262,7 @@ class ParaformerHip:
         din = list(din)[:batch_in]
         if len_ is not None:
             din = [np.asarray(x)[:n] for x, n in zip(din, len_)]
-        r = self.forward_ids(din)
+        r = self.forward_ids(din, hw_emb=hw_emb if self._lib.pfhip_is_contextual(self._h) else None)
         res = []
         for ids in r["ids"]:
             if self._vocab is not None:

@@ -54,7 +54,7 @@ struct Tensor {
 
 struct Config {
   int d_model = 512, n_head = 4, ffn = 2048, enc_layers = 50, dec_layers = 16, dec_ffn = 2048;
-  int kernel = 11, vocab = 8404, n_mels = 80, lfr_m = 7, lfr_n = 6, pred_residual = 0;
+  int kernel = 11, vocab = 8404, n_mels = 80, lfr_m = 7, lfr_n = 6, pred_residual = 0, contextual = 0;
   float cif_threshold = 1.0f, tail_threshold = 0.45f, smooth_factor = 1.0f, noise_threshold = 0.0f;
   int sample_rate = 16000;
 };
@@ -114,7 +114,8 @@ struct pfhip_model {
 
   // workspace
   Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
-  Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta;
+  Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw;
+  int n_hw = 0;                  // hotword embeddings resident in `hw` ([n_hw, d])
   void* h_meta = nullptr; size_t h_meta_cap = 0;     // pinned
   int* h_counts = nullptr;                            // pinned [2*B]
   size_t h_counts_cap = 0;
@@ -127,7 +128,7 @@ struct pfhip_model {
   int *m_frame_off = nullptr, *m_nframes = nullptr, *m_row_off = nullptr, *m_len = nullptr,
       *m_row_pos = nullptr, *m_row_len = nullptr;
   int64_t* m_sample_off = nullptr;
-  int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr;
+  int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr, *m_hw_off = nullptr, *m_hw_len = nullptr;
 
   // profiling
   int prof_mask = 0;             // bit c set -> launches of kernel class c are bracketed by events

@@ -86,6 +86,14 @@ void launch_cif(const float* hidden, int ldh, const float* alphas, const int* ro
 void launch_compact(const float* stage, float* emb, const int* tok_row_src, int ML, int D,
                     hipStream_t s);
 
+// ---- hotword embedder ------------------------------------------------------------
+// out[r] = table[ids[r]]  (Embedding lookup, D % 4 == 0)
+void launch_gather_rows(const int32_t* ids, const float* table, int D, float* out, int R, hipStream_t s);
+// One LSTM step on pre-activations G [H, 4D] (torch gate order i,f,g,o): c = sig(f)*c + sig(i)*tanh(g);
+// h = sig(o)*tanh(c); rows with lens[j]-1 == t also copy h into sel[j].
+void launch_lstm_cell(const float* G, float* c, float* h, const int32_t* lens, int t, float* sel, int H, int D,
+                      hipStream_t s);
+
 // ---- head -----------------------------------------------------------------
 // per row: log-softmax over V logits, argmax (first max wins, util.cpp:63-74).  logp may be null.
 void launch_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids,

@@ -132,6 +132,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   c.lfr_m = (int)jc->number("lfr_m", c.lfr_m);
   c.lfr_n = (int)jc->number("lfr_n", c.lfr_n);
   c.pred_residual = (int)jc->number("pred_residual", 0);
+  c.contextual = (int)jc->number("contextual", 0);
   c.cif_threshold = (float)jc->number("cif_threshold", c.cif_threshold);
   c.tail_threshold = (float)jc->number("tail_threshold", c.tail_threshold);
   c.smooth_factor = (float)jc->number("smooth_factor", c.smooth_factor);
@@ -202,6 +203,14 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   }
   ok = ok && need_ffn("dec3.") && need("dec.after_norm.g", {d}) && need("dec.after_norm.b", {d}) &&
        need("dec.out.w", {c.vocab, d}) && need("dec.out.b", {c.vocab});
+  if (ok && c.contextual) {      // contextual (hotword) model: bias embedder + bias decoder
+    if (c.dec_layers < 1) return fail(PFHIP_ERR_FORMAT, "contextual model needs a decoder");
+    ok = need("bias.embed.w", {c.vocab, d}) && need("bias.lstm.w_ih", {4 * d, d}) && need("bias.lstm.w_hh", {4 * d, d}) &&
+         need("bias.lstm.b_ih", {4 * d}) && need("bias.lstm.b_hh", {4 * d}) && need("bias.dec.norm3.g", {d}) &&
+         need("bias.dec.norm3.b", {d}) && need("bias.dec.q.w", {d, d}) && need("bias.dec.q.b", {d}) &&
+         need("bias.dec.kv.w", {2 * d, d}) && need("bias.dec.kv.b", {2 * d}) && need("bias.dec.out.w", {d, d}) &&
+         need("bias.dec.out.b", {d}) && need("bias.out.w", {d, 2 * d});
+  }
   if (!ok) return PFHIP_ERR_FORMAT;
 
   // ---- repacks ---------------------------------------------------------------------------------------
@@ -407,11 +416,13 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   }
   m->ML = ML;
   if (ML == 0) { HIP_TRY(hipGetLastError()); return PFHIP_OK; }
+  if (c.contextual && m->n_hw <= 0)       // the reference logs "hw_emb is null" and returns empty results (paraformer.cpp:516-520)
+    return fail(PFHIP_ERR_ARG, "contextual model needs hotword embeddings (pfhip_set_hotwords / hw_emb)");
   const int MLp = round_up(ML, pfhip::kTileM);
 
   // ---- decoder-side metadata + workspace -------------------------------------------------------------
   {
-    const size_t n = 2 * (size_t)B + ML;
+    const size_t n = 4 * (size_t)B + ML;
     HIP_TRY(m->dmeta.ensure(n * 4));
     // second half of the pinned staging buffer: never overwritten while an earlier copy may be in flight
     if (m->h_meta_cap / 2 + n * 4 > m->h_meta_cap) return fail(PFHIP_ERR_CAPACITY, "internal: metadata staging too small");
@@ -419,9 +430,11 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     int* dm = m->dmeta.i();
     std::memcpy(hm, m->tok_off.data(), 4 * B); m->m_tok_off = dm;
     std::memcpy(hm + B, m->n_fires.data(), 4 * B); m->m_tok_len = dm + B;
-    m->m_src_row = dm + 2 * B;
+    for (int b = 0; b < B; ++b) { hm[2 * B + b] = 0; hm[3 * B + b] = m->n_hw; }      // every utterance sees the same hotwords
+    m->m_hw_off = dm + 2 * B; m->m_hw_len = dm + 3 * B;
+    m->m_src_row = dm + 4 * B;
     for (int b = 0; b < B; ++b)
-      for (int n2 = 0; n2 < m->n_fires[b]; ++n2) hm[2 * B + m->tok_off[b] + n2] = m->row_off[b] + b + n2;
+      for (int n2 = 0; n2 < m->n_fires[b]; ++n2) hm[4 * B + m->tok_off[b] + n2] = m->row_off[b] + b + n2;
     HIP_TRY(hipMemcpyAsync(dm, hm, n * 4, hipMemcpyHostToDevice, s));
   }
   HIP_TRY(m->emb.ensure((size_t)MLp * d * 4));
@@ -471,7 +484,28 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
       pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
                               m->m_row_off, m->m_len, B, c.n_head, m->maxL, att_scale, s);
     }
-    gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
+    if (!(c.contextual && i == c.dec_layers - 1)) {
+      gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
+      continue;
+    }
+    // ---- contextual last layer (UPSTREAM ContextualDecoderLayer + ContextualBiasDecoder + bias_output):
+    //      x = x_self_attn + W_b [x_src_attn | cx],  cx = cross-attention of norm3_b(x_self_attn) over the hotword
+    //      embeddings; xd holds x_self_attn, cat = [x_src_attn | cx] with row stride 2d.
+    HIP_TRY(m->cat.ensure((size_t)MLp * 2 * d * 4));
+    float* cat = m->cat.f();
+    gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, cat, 2 * d, m->W(p + "out.b").d, nullptr, 0, nullptr, 0, ML, false);
+    lnorm(m, s, xd, d, m->yd.f(), d, "bias.dec.norm3", ML, d, d);
+    gemm(m, s, m->yd.f(), d, m->W("bias.dec.q.w").d, d, d, d, m->qd.f(), d, m->W("bias.dec.q.b").d, nullptr, 0, nullptr, 0, ML, false);
+    gemm(m, s, m->hw.f(), d, m->W("bias.dec.kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W("bias.dec.kv.b").d, nullptr, 0, nullptr, 0,
+         m->n_hw, false);
+    {
+      Scope sc(m, s, K_ATTN, 4.0 * ML * (double)m->n_hw * d, 8.0 * ML * d);
+      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
+                              m->m_hw_off, m->m_hw_len, B, c.n_head, m->maxL, att_scale, s);
+    }
+    gemm(m, s, m->ctxd.f(), d, m->W("bias.dec.out.w").d, d, d, d, cat + d, 2 * d, m->W("bias.dec.out.b").d, nullptr, 0, nullptr,
+         0, ML, false);
+    gemm(m, s, cat, 2 * d, m->W("bias.out.w").d, d, 2 * d, 2 * d, xd, d, nullptr, xd, d, nullptr, 0, ML, false);
   }
   dec_ffn("dec3.", xd, m->td.f());
   lnorm(m, s, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
@@ -529,6 +563,15 @@ pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
   return PFHIP_OK;
 }
 
+pfhip_status set_hotwords_locked(pfhip_model* m, const float* hw_emb, int H, hipStream_t s) {
+  const int d = m->cfg.d_model;
+  HIP_TRY(m->hw.ensure((size_t)round_up(H, pfhip::kTileM) * d * 4));
+  HIP_TRY(hipMemcpyAsync(m->hw.p, hw_emb, (size_t)H * d * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  m->n_hw = H;
+  return PFHIP_OK;
+}
+
 pfhip_status stage_pcm(pfhip_model* m, const float* const* pcm, const int* n_samples, int B, hipStream_t s,
                        std::vector<int64_t>& off) {
   off.assign(B, 0);
@@ -577,7 +620,7 @@ void pfhip_destroy(pfhip_model* m) {
   (void)hipDeviceSynchronize();
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
-                 &m->logits, &m->logp, &m->ids, &m->dmeta})
+                 &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts})
@@ -618,12 +661,16 @@ pfhip_status pfhip_offline_fetch(pfhip_model* m, pfhip_out* out) {
 pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,
                                    const float* hw_emb, int n_hotwords, pfhip_out* out) {
   g_err.clear();
-  (void)hw_emb; (void)n_hotwords;   // plain (non-contextual) model ignores hw_emb: paraformer.cpp:515 use_hotword=false
   if (!m || !pcm || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
   std::lock_guard<std::mutex> lk(m->mu);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->own_stream;
   m->prof_stream = s;
+  if (m->cfg.contextual) {          // plain models ignore hw_emb (paraformer.cpp:515: use_hotword == false)
+    if (!hw_emb || n_hotwords <= 0) return fail(PFHIP_ERR_ARG, "hw_emb is null");          // paraformer.cpp:516-520
+    pfhip_status hs = set_hotwords_locked(m, hw_emb, n_hotwords, s);
+    if (hs) return hs;
+  }
   std::vector<int64_t> off;
   pfhip_status st = stage_pcm(m, pcm, n_samples, batch, s, off);
   if (st) return st;
@@ -632,6 +679,58 @@ pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, cons
   st = head_locked(m, s, out->logp != nullptr);
   if (st) return st;
   return fetch_locked(m, out, s);
+}
+
+pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwords) {
+  g_err.clear();
+  if (!m || !hw_emb || n_hotwords <= 0) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  return set_hotwords_locked(m, hw_emb, n_hotwords, m->own_stream);
+}
+
+int pfhip_is_contextual(const pfhip_model* m) { return m ? m->cfg.contextual : 0; }
+
+// model_eb.onnx Run + row selection (paraformer.cpp:656-685): Embedding -> 1-layer LSTM over the 10 padded positions,
+// output of hotword j taken at step lengths[j]-1.
+pfhip_status pfhip_hotword_embed(pfhip_model* m, const int32_t* hotword_matrix, const int32_t* lengths, int n_hotwords,
+                                 float* out) {
+  g_err.clear();
+  if (!m || !hotword_matrix || !lengths || n_hotwords <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
+  if (!m->cfg.contextual) return fail(PFHIP_ERR_UNSUPPORTED, "model has no hotword embedder (use_hotword == false)");
+  const int H = n_hotwords, L = 10, d = m->cfg.d_model;
+  for (int j = 0; j < H; ++j) {
+    if (lengths[j] < 1 || lengths[j] > L) return fail(PFHIP_ERR_ARG, "hotword length outside 1..10");
+    for (int t = 0; t < L; ++t)
+      if (hotword_matrix[j * L + t] < 0 || hotword_matrix[j * L + t] >= m->cfg.vocab) return fail(PFHIP_ERR_ARG, "hotword id outside the vocabulary");
+  }
+  std::lock_guard<std::mutex> lk(m->mu);
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->own_stream;
+  const int R = L * H, Rp = round_up(R, pfhip::kTileM), Hp = round_up(H, pfhip::kTileM);
+  Buf ids, lens, X, GX, G, hc;
+  struct Free { Buf* b[6]; ~Free() { for (Buf* x : b) x->release(); } } fr{{&ids, &lens, &X, &GX, &G, &hc}};
+  HIP_TRY(ids.ensure((size_t)R * 4)); HIP_TRY(lens.ensure((size_t)H * 4));
+  HIP_TRY(X.ensure((size_t)Rp * d * 4)); HIP_TRY(GX.ensure((size_t)(Rp + pfhip::kTileM) * 4 * d * 4)); HIP_TRY(G.ensure((size_t)Hp * 4 * d * 4));
+  HIP_TRY(hc.ensure((size_t)3 * Hp * d * 4));
+  // time-major ids: row t*H + j = token t of hotword j
+  std::vector<int32_t> tm((size_t)R);
+  for (int j = 0; j < H; ++j) for (int t = 0; t < L; ++t) tm[(size_t)t * H + j] = hotword_matrix[j * L + t];
+  HIP_TRY(hipMemcpyAsync(ids.p, tm.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(lens.p, lengths, (size_t)H * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(hc.p, 0, (size_t)3 * Hp * d * 4, s));
+  float* h = hc.f(); float* cst = h + (size_t)Hp * d; float* sel = cst + (size_t)Hp * d;
+  pfhip::launch_gather_rows(static_cast<const int32_t*>(ids.p), m->W("bias.embed.w").d, d, X.f(), R, s);
+  gemm(m, s, X.f(), d, m->W("bias.lstm.w_ih").d, 4 * d, d, d, GX.f(), 4 * d, m->W("bias.lstm.b_ih").d, nullptr, 0, nullptr, 0, R, false);
+  for (int t = 0; t < L; ++t) {
+    gemm(m, s, h, d, m->W("bias.lstm.w_hh").d, 4 * d, d, d, G.f(), 4 * d, m->W("bias.lstm.b_hh").d, GX.f() + (size_t)t * H * 4 * d,
+         4 * d, nullptr, 0, H, false);
+    pfhip::launch_lstm_cell(G.f(), cst, h, static_cast<const int32_t*>(lens.p), t, sel, H, d, s);
+  }
+  HIP_TRY(hipMemcpyAsync(out, sel, (size_t)H * d * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return PFHIP_OK;
 }
 
 pfhip_status pfhip_extract_feats(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,

@@ -228,7 +228,48 @@ __global__ __launch_bounds__(128) void compact_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(d + c) = *reinterpret_cast<const float4*>(s + c);
 }
 
+__global__ __launch_bounds__(128) void gather_rows_kernel(const int32_t* __restrict__ ids,
+                                                          const float* __restrict__ table, int D,
+                                                          float* __restrict__ out, int R) {
+  const int r = blockIdx.x;
+  if (r >= R) return;
+  const float* src = table + (size_t)ids[r] * D;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4)
+    *reinterpret_cast<float4*>(out + (size_t)r * D + c) = *reinterpret_cast<const float4*>(src + c);
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ G, float* __restrict__ c,
+                                                        float* __restrict__ h, const int32_t* __restrict__ lens,
+                                                        int t, float* __restrict__ sel, int H, int D) {
+  const int j = blockIdx.x;
+  if (j >= H) return;
+  const float* g = G + (size_t)j * 4 * D;
+  const bool pick = lens[j] - 1 == t;
+  for (int k = threadIdx.x; k < D; k += blockDim.x) {
+    const float ig = 1.0f / (1.0f + expf(-g[k]));
+    const float fg = 1.0f / (1.0f + expf(-g[D + k]));
+    const float gg = tanhf(g[2 * D + k]);
+    const float og = 1.0f / (1.0f + expf(-g[3 * D + k]));
+    const float cn = fg * c[(size_t)j * D + k] + ig * gg;
+    const float hn = og * tanhf(cn);
+    c[(size_t)j * D + k] = cn;
+    h[(size_t)j * D + k] = hn;
+    if (pick) sel[(size_t)j * D + k] = hn;
+  }
+}
+
 }  // namespace
+
+void launch_gather_rows(const int32_t* ids, const float* table, int D, float* out, int R, hipStream_t s) {
+  if (R <= 0) return;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(R), dim3(128), 0, s, ids, table, D, out, R);
+}
+
+void launch_lstm_cell(const float* G, float* c, float* h, const int32_t* lens, int t, float* sel, int H, int D,
+                      hipStream_t s) {
+  if (H <= 0) return;
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(H), dim3(256), 0, s, G, c, h, lens, t, sel, H, D);
+}
 
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
                       int M, int D, int Dout, float eps, hipStream_t s) {

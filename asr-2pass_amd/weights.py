@@ -88,6 +88,18 @@ def tensor_specs(cfg):
     lin("dec3.ffn2", d, fd, bias=False)
     ln("dec.after_norm", d)
     lin("dec.out", V, d)
+    if cfg.get("contextual", 0):
+        # hotword embedder (model_eb.onnx: Embedding + 1-layer LSTM) and the bias decoder of the last layer
+        specs.append(("bias.embed.w", [V, d], ("normal", 1.0)))
+        specs.append(("bias.lstm.w_ih", [4 * d, d], ("normal", 1.0 / math.sqrt(d))))
+        specs.append(("bias.lstm.w_hh", [4 * d, d], ("normal", 1.0 / math.sqrt(d))))
+        specs.append(("bias.lstm.b_ih", [4 * d], ("normal", 0.1)))
+        specs.append(("bias.lstm.b_hh", [4 * d], ("normal", 0.1)))
+        ln("bias.dec.norm3", d)
+        lin("bias.dec.q", d, d)
+        lin("bias.dec.kv", 2 * d, d)
+        lin("bias.dec.out", d, d)
+        specs.append(("bias.out.w", [d, 2 * d], ("normal", 1.0 / math.sqrt(2 * d))))
     return specs
 
 

@@ -91,6 +91,19 @@ pfhip_status pfhip_offline_enqueue(pfhip_model* m, const float* d_pcm, const int
                                    const int* n_samples, int batch, void* stream);
 pfhip_status pfhip_offline_fetch(pfhip_model* m, pfhip_out* out);
 
+/* ---- hotwords (contextual model) ---------------------------------------------------------------
+ *   pfhip_hotword_embed <-> the `hw_m_session->Run` on model_eb.onnx + the per-hotword row selection inside
+ *                           Paraformer::CompileHotwordEmbedding (paraformer.cpp:656-685): ids i32 [H,10] (0-padded, last row
+ *                           [1,0,...] appended by the caller, :648-651) + lengths [H] -> f32 [H, d] = LSTM output at step len-1.
+ *                           The string -> id part (:601-647: split, seg_dict, vocabulary) is host text handling above this.
+ *   pfhip_set_hotwords  <-> the `hw_emb` argument of Model::Forward kept resident for pfhip_offline_enqueue;
+ *                           pfhip_offline_forward takes hw_emb [H, d] per call like the reference (paraformer.cpp:515-531).
+ * A contextual model without hotwords is an error ("hw_emb is null", :516-520); a plain model ignores them. */
+int pfhip_is_contextual(const pfhip_model* m);
+pfhip_status pfhip_hotword_embed(pfhip_model* m, const int32_t* hotword_matrix, const int32_t* lengths, int n_hotwords,
+                                 float* out);
+pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwords);
+
 /* ---- front end only ----------------------------------------------------------------------------
  * Replaces Paraformer::FbankKaldi + LfrCmvn (paraformer.cpp:309-323, 421-461) on their own:
  * feats_out gets sum(n_frames)*feat_dim floats, utterances back to back; n_frames_out [batch]. */

@@ -197,11 +197,58 @@ def decoder_layer(x, mem, W, pfx, n_head):
     return x
 
 
-def decoder(emb, mem, W):
+def hotword_embed(hotword_matrix, lengths, W):
+    """model_eb.onnx + row selection (paraformer.cpp:656-685).  UPSTREAM: Embedding(vocab, d) -> LSTM(d, d), torch gate
+    order i,f,g,o; output [10, H, d], row len_j-1 of hotword j is its embedding."""
+    ids = np.asarray(hotword_matrix, np.int64)
+    H, L = ids.shape
+    d = W.cfg["d_model"]
+    x = W["bias.embed.w"][ids].astype(F32)                     # [H, L, d]
+    w_ih, w_hh = W["bias.lstm.w_ih"], W["bias.lstm.w_hh"]
+    b_ih, b_hh = W["bias.lstm.b_ih"], W["bias.lstm.b_hh"]
+    h = np.zeros((H, d), F32)
+    c = np.zeros((H, d), F32)
+    out = np.zeros((H, d), F32)
+    sig = lambda z: (F32(1) / (F32(1) + np.exp(-z))).astype(F32)
+    for t in range(L):
+        g = (x[:, t] @ w_ih.T + b_ih + h @ w_hh.T + b_hh).astype(F32)
+        i_, f_, g_, o_ = g[:, :d], g[:, d:2 * d], g[:, 2 * d:3 * d], g[:, 3 * d:]
+        c = (sig(f_) * c + sig(i_) * np.tanh(g_)).astype(F32)
+        h = (sig(o_) * np.tanh(c)).astype(F32)
+        pick = np.asarray(lengths) - 1 == t
+        out[pick] = h[pick]
+    return out
+
+
+def contextual_last_layer(x, mem, hw_emb, W, pfx, n_head):
+    """UPSTREAM ContextualDecoderLayer + ContextualBiasDecoder + bias_output: the last decoder
+    layer's cross-attention output is concatenated with a cross-attention over the hotword embeddings and projected
+    2d -> d, then added to the layer's self-attention (FSMN) output."""
+    residual = x
+    t = decoder_ffn(layer_norm(x, W[pfx + "norm1.g"], W[pfx + "norm1.b"]), W, pfx)
+    t2 = layer_norm(t, W[pfx + "norm2.g"], W[pfx + "norm2.b"])
+    x_self = (residual + fsmn(t2, W[pfx + "fsmn.w"])).astype(F32)
+    d = x.shape[1]
+    y = layer_norm(x_self, W[pfx + "norm3.g"], W[pfx + "norm3.b"])
+    q = linear(y, W[pfx + "q.w"], W[pfx + "q.b"])
+    kv = linear(mem, W[pfx + "kv.w"], W[pfx + "kv.b"])
+    x_src = linear(mha(q, kv[:, :d], kv[:, d:], n_head), W[pfx + "out.w"], W[pfx + "out.b"])
+    yb = layer_norm(x_self, W["bias.dec.norm3.g"], W["bias.dec.norm3.b"])
+    qb = linear(yb, W["bias.dec.q.w"], W["bias.dec.q.b"])
+    kvb = linear(hw_emb, W["bias.dec.kv.w"], W["bias.dec.kv.b"])
+    cx = linear(mha(qb, kvb[:, :d], kvb[:, d:], n_head), W["bias.dec.out.w"], W["bias.dec.out.b"])
+    merged = linear(np.concatenate([x_src, cx], axis=1), W["bias.out.w"])
+    return (x_self + merged).astype(F32)
+
+
+def decoder(emb, mem, W, hw_emb=None):
     cfg = W.cfg
     x = emb
     for i in range(cfg["dec_layers"]):
-        x = decoder_layer(x, mem, W, f"dec.{i}.", cfg["n_head"])
+        if cfg.get("contextual", 0) and i == cfg["dec_layers"] - 1:
+            x = contextual_last_layer(x, mem, hw_emb, W, f"dec.{i}.", cfg["n_head"])
+        else:
+            x = decoder_layer(x, mem, W, f"dec.{i}.", cfg["n_head"])
     # decoders3: FFN-only layer, NO residual (UPSTREAM DecoderLayerSANM with self_attn=src_attn=None)
     x = decoder_ffn(layer_norm(x, W["dec3.norm1.g"], W["dec3.norm1.b"]), W, "dec3.")
     x = layer_norm(x, W["dec.after_norm.g"], W["dec.after_norm.b"])
@@ -223,7 +270,7 @@ def greedy_search(logp, n_len):
     return [find_max(logp[i])[1] for i in range(min(n_len, logp.shape[0]))]
 
 
-def forward_feats(feats, W, stages=None):
+def forward_feats(feats, W, stages=None, hw_emb=None):
     """feats [T, 560] -> dict(logp [L, V], token_num, alphas [T+1], enc [T, d], emb [L, d], ids)."""
     enc = encoder(feats, W)
     hidden, alphas = predictor_alphas(enc, W)
@@ -233,7 +280,7 @@ def forward_feats(feats, W, stages=None):
     emb, fires = cif(hidden, alphas, W.cfg["cif_threshold"])
     res = dict(enc=enc, alphas=alphas, token_num=token_num, emb=emb, fires=fires)
     if emb.shape[0] > 0:
-        logp = decoder(emb, enc, W)
+        logp = decoder(emb, enc, W, hw_emb)
     else:
         logp = np.zeros((0, W.cfg["vocab"]), F32)
     res["logp"] = logp
@@ -241,11 +288,11 @@ def forward_feats(feats, W, stages=None):
     return res
 
 
-def forward_pcm(waves, W):
+def forward_pcm(waves, W, hw_emb=None):
     """Model::Forward for one utterance: pcm [-1,1) float32 -> result dict (paraformer.cpp:463-589)."""
     feats = frontend.extract_feats(waves, W["cmvn.mean"], W["cmvn.istd"])
     if feats.shape[0] == 0:
         return dict(feats=feats, logp=np.zeros((0, W.cfg["vocab"]), F32), token_num=0, ids=[])
-    r = forward_feats(feats, W)
+    r = forward_feats(feats, W, hw_emb=hw_emb)
     r["feats"] = feats
     return r

@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
     "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
+    "pfhip_timestamp_onnx",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
 ]
 
@@ -106,6 +107,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_vadseg_destroy.restype = None
     lib.pfhip_vadseg_reset.argtypes = [vp]
     lib.pfhip_vadseg_feed.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ctypes.c_float, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.pfhip_timestamp_onnx.argtypes = [vp, vp, ci, ci, ctypes.c_float, ctypes.c_float, vp, ci, ctypes.POINTER(ci)]
     lib.pfhip_punc_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
     lib.pfhip_punc_destroy.argtypes = [vp]
     lib.pfhip_punc_destroy.restype = None
@@ -497,3 +499,16 @@ class E2EVadModelHost:
                                                       float(speech_noise_thres), int(sample_rate), segs.ctypes.data, cap,
                                                       ctypes.byref(n)))
         return [[int(a), int(b)] for a, b in segs[:n.value]]
+
+
+def timestamp_onnx(us_alphas, us_cif_peak, n_chars, begin_time=0.0, total_offset=-1.5):
+    """`funasr::TimestampOnnx` (onnxruntime/src/util.cpp:838-963) through the C ABI: [(begin_s, end_s, is_sil)]."""
+    lib = load_lib()
+    a = np.ascontiguousarray(us_alphas, dtype=np.float32).copy()
+    p = np.ascontiguousarray(us_cif_peak, dtype=np.float32)
+    cap = 2 * (n_chars + 4) + 8
+    spans = np.zeros((cap, 3), np.float32)
+    n = ctypes.c_int(0)
+    _check(lib, lib.pfhip_timestamp_onnx(a.ctypes.data, p.ctypes.data, int(p.size), int(n_chars), float(begin_time),
+                                         float(total_offset), spans.ctypes.data, cap, ctypes.byref(n)))
+    return [(float(s[0]), float(s[1]), bool(s[2])) for s in spans[:n.value]]

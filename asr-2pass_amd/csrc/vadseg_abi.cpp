@@ -2,6 +2,7 @@
 #include <new>
 
 #include "../../include/pfhip.h"
+#include "host/timestamp.h"
 #include "host/vad_segmenter.h"
 #include "internal.h"
 
@@ -34,6 +35,18 @@ pfhip_status pfhip_vadseg_feed(pfhip_vadseg* s, const float* sil_prob, int n_fra
   *n_segments = (int)segs.size();
   if ((int)segs.size() > cap_pairs) return pfhip_detail::fail(PFHIP_ERR_CAPACITY, "segment buffer too small");
   for (size_t i = 0; i < segs.size(); ++i) { segments[2 * i] = segs[i].start_ms; segments[2 * i + 1] = segs[i].end_ms; }
+  return PFHIP_OK;
+}
+
+pfhip_status pfhip_timestamp_onnx(float* us_alphas, const float* us_cif_peak, int n_frames3, int n_chars, float begin_time_ms,
+                                  float total_offset, float* spans, int cap_spans, int* n_spans) {
+  if (!us_alphas || !us_cif_peak || n_frames3 < 0 || !n_spans) return pfhip_detail::fail(PFHIP_ERR_ARG, "bad argument");
+  std::vector<float> a(us_alphas, us_alphas + n_frames3), p(us_cif_peak, us_cif_peak + n_frames3);
+  const auto r = pfhip_host::TimestampOnnx(a, p, n_chars, begin_time_ms, total_offset);
+  for (int i = 0; i < n_frames3; ++i) us_alphas[i] = a[i];
+  *n_spans = (int)r.size();
+  if ((int)r.size() > cap_spans) return pfhip_detail::fail(PFHIP_ERR_CAPACITY, "span buffer too small");
+  for (size_t i = 0; i < r.size(); ++i) { spans[3 * i] = r[i].begin_s; spans[3 * i + 1] = r[i].end_s; spans[3 * i + 2] = r[i].is_sil ? 1.f : 0.f; }
   return PFHIP_OK;
 }
 

@@ -171,6 +171,13 @@ pfhip_status pfhip_vadseg_feed(pfhip_vadseg* s, const float* sil_prob, int n_fra
                                float speech_noise_thres, int sample_rate, int32_t* segments, int cap_pairs,
                                int* n_segments);
 
+/* ---- token time stamps (host logic) ------------------------------------------------------------------
+ * `funasr::TimestampOnnx` (onnxruntime/src/util.cpp:838-963) restated on the host: us_alphas / us_cif_peak [3T] of the
+ * time-stamp model + the number of recognised tokens (without "</s>") -> (begin_s, end_s) spans; spans[3*i+2] != 0 marks
+ * an inserted <sil>.  us_alphas is rescaled in place like the reference's by-reference argument. */
+pfhip_status pfhip_timestamp_onnx(float* us_alphas, const float* us_cif_peak, int n_frames3, int n_chars, float begin_time_ms,
+                                  float total_offset, float* spans, int cap_spans, int* n_spans);
+
 /* ---- CT-Transformer punctuation forward ------------------------------------------------------------
  *   pfhip_punc_create_from_memory <-> CTTransformer::InitPunc session load (ct-transformer.cpp:14-37)
  *   pfhip_punc_infer              <-> CTTransformer::Infer (ct-transformer.cpp:162-204): ids [n] -> punctuation id

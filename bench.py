@@ -58,6 +58,17 @@ def max_over_ranks(dt: float, dist, device):
     return float(t.item())
 
 
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01/pmc_hbm_traffic.json: FETCH_SIZE x2 +
+    WRITE_SIZE, collected with rocprofv3 in separate --pmc runs of this same command); PMC counters cannot be read from
+    inside the timed run, so this is the last profiled value, or null when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")) as f:
+            return json.load(f)["gemm_avg_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(man, blob, utts, seconds_per_utt):
     """The oracle (CPU restatement, numpy/OpenBLAS fp32) timed in the reference's threading shape:
     W worker threads sharing one model, 1 BLAS thread each, batch 1 per call
@@ -185,9 +196,10 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
             out["roofline"] = {
                 "bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                 "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches_per_step": g["launches"] / args.steps,
                 "flops_per_launch": g["flops"] / max(1, g["launches"]),
+                "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
                 "per_class_ms_untimed_pass": {k: v["ms"] for k, v in prof_all.items()},
                 "per_class_tflops_untimed_pass": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)
                                                   for k, v in prof_all.items() if v["flops"] > 0},

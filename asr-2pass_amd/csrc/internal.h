@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -29,18 +30,22 @@ inline pfhip_status fail(pfhip_status st, const std::string& msg) {
       return pfhip_detail::fail(PFHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+// bumped whenever a workspace buffer is (re)allocated or freed: cached hipGraphs hold raw pointers
+std::atomic<uint64_t>& buf_epoch();          // pfhip.cpp
+
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    buf_epoch().fetch_add(1);
     if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
     bytes = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipSuccess) cap = bytes;
     return e;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) { (void)hipFree(p); buf_epoch().fetch_add(1); } p = nullptr; cap = 0; }
   float* f() const { return static_cast<float*>(p); }
   int* i() const { return static_cast<int*>(p); }
 };

@@ -24,6 +24,10 @@
 #include "json_min.h"
 
 namespace pfhip_detail {
+std::atomic<uint64_t>& buf_epoch() {
+  static std::atomic<uint64_t> e{1};
+  return e;
+}
 std::string& last_error() {
   thread_local std::string e;
   return e;

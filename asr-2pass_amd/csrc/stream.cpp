@@ -10,6 +10,7 @@
 // The host keeps only counters (cache lengths, start_idx_cache_, first/last flags) and the < 400 left-over
 // PCM samples of input_cache_ (:123-127).  `reserve_waveforms_` is dead state in the reference (it only feeds
 // its own index arithmetic, :162-171,180-182) and is not kept.
+#include <map>
 #include <memory>
 
 #include "internal.h"
@@ -33,6 +34,11 @@ struct pfhip_stream {
   int last_n = 0, last_fires = 0;
   bool last_has_logp = false;
   bool debug = false;
+  // hipGraph cache of the two launch sequences of a chunk (encoder+CIF keyed by window rows / last flag, decoder
+  // keyed by fired tokens and window rows): a chunk is ~700 launches and launch-bound when issued one by one
+  std::map<int, hipGraphExec_t> graphs;
+  uint64_t graphs_epoch = 0;
+  bool use_graphs = true;
 };
 
 namespace {
@@ -81,6 +87,35 @@ void reset_cache(pfhip_stream* s) {
   s->n_splice = 0;
 }
 
+void drop_graphs(pfhip_stream* s) {
+  for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+  s->graphs.clear();
+}
+
+// Runs `enqueue` on `st`, through a cached hipGraph when allowed: first use of a key captures the launches,
+// later uses replay them (one host call instead of hundreds).
+template <typename F>
+pfhip_status run_cached(pfhip_stream* s, int key, bool allow, hipStream_t st, F&& enqueue) {
+  if (!allow) return enqueue();
+  if (s->graphs_epoch != buf_epoch().load()) { drop_graphs(s); s->graphs_epoch = buf_epoch().load(); }
+  auto it = s->graphs.find(key);
+  if (it == s->graphs.end()) {
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    pfhip_status rc = enqueue();
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(PFHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(PFHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    it = s->graphs.emplace(key, ge).first;
+  }
+  HIP_TRY(hipGraphLaunch(it->second, st));
+  return PFHIP_OK;
+}
+
 // ForwardChunk (:415-523) on the window already assembled in s->chunk (n rows).  Appends ids to `out`.
 pfhip_status forward_chunk(pfhip_stream* s, int n, hipStream_t st, std::vector<int32_t>& out, bool want_logp) {
   pfhip_model* m = s->m;
@@ -105,43 +140,45 @@ pfhip_status forward_chunk(pfhip_stream* s, int n, hipStream_t st, std::vector<i
   HIP_TRY(m->ctxd.ensure((size_t)128 * d * 4));
   HIP_TRY(m->xd.ensure((size_t)128 * d * 4));
   HIP_TRY(m->logits.ensure((size_t)128 * m->vocab_pad * 4));
-  // device metadata: [0] off=0, [1] len=n (encoder rows), [2] tok_len (set after CIF), row_pos[n], row_len[n]
+  if (want_logp) HIP_TRY(s->logp.ensure((size_t)128 * c.vocab * 4));
+  const bool graphs = s->use_graphs && !want_logp && m->prof_mask == 0;
+  // device metadata: [0] off=0, [1] len=n (encoder rows), [2] tok_len (set after CIF), [16..] row_pos[n], row_len[n]
   int* dm = s->meta.i();
-  {
+  int* d_off = dm; int* d_len = dm + 1; int* d_tok = dm + 2;
+  {   // pinned staging is filled BEFORE the (possibly replayed) copies read it
     int* hm = s->h_pin + 256;
     hm[0] = 0; hm[1] = n; hm[2] = 0;
-    HIP_TRY(hipMemcpyAsync(dm, hm, 12, hipMemcpyHostToDevice, st));
+    int* hr = s->h_pin + 512;
+    for (int t = 0; t < n; ++t) { hr[t] = t; hr[128 + t] = n; }
   }
-  int* d_off = dm; int* d_len = dm + 1; int* d_tok = dm + 2;
-
-  // ---- streaming encoder session (:448): SAN-M stack on the window as given (no scale/PE inside) --------
+  const int is_last = s->is_last_chunk ? 1 : 0;
   float* x = m->x.f();
-  for (int i = 0; i < c.enc_layers; ++i) {
-    const std::string p = "enc." + std::to_string(i) + ".";
-    const bool first = i == 0;
-    const float* xin = first ? s->chunk.f() : x;
-    const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
-    lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", n, Din, Kp);
-    gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
-         m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, n, false);
-    pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, 1, n, d, st);
-    pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
-                            d_len, d_off, d_len, 1, c.n_head, n, att_scale, st);
-    gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
-         first ? nullptr : x, d, n, false);
-    lnorm(m, st, x, d, m->y.f(), d, p + "norm2", n, d, d);
-    gemm(m, st, m->y.f(), d, m->W(p + "ffn1.w").d, c.ffn, d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0,
-         nullptr, 0, n, true);
-    gemm(m, st, m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, d, c.ffn, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0,
-         n, false);
-  }
-  lnorm(m, st, x, d, s->enc.f(), d, "enc.after_norm", n, d, d);
-  // predictor alphas: conv1d k=3 over the window (zero padded at its ends) -> relu -> linear -> sigmoid
-  {
-    // row_pos / row_len for the im2col of one segment of n rows
-    int* hm = s->h_pin + 512;
-    for (int t = 0; t < n; ++t) { hm[t] = t; hm[128 + t] = n; }
-    HIP_TRY(hipMemcpyAsync(dm + 16, hm, 256 * 4, hipMemcpyHostToDevice, st));
+
+  pfhip_status rc = run_cached(s, (n << 1) | is_last, graphs, st, [&]() -> pfhip_status {
+    HIP_TRY(hipMemcpyAsync(dm, s->h_pin + 256, 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dm + 16, s->h_pin + 512, 256 * 4, hipMemcpyHostToDevice, st));
+    // ---- streaming encoder session (:448): SAN-M stack on the window as given (no scale/PE inside) --------
+    for (int i = 0; i < c.enc_layers; ++i) {
+      const std::string p = "enc." + std::to_string(i) + ".";
+      const bool first = i == 0;
+      const float* xin = first ? s->chunk.f() : x;
+      const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
+      lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", n, Din, Kp);
+      gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
+           m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, n, false);
+      pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, 1, n, d, st);
+      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                              d_len, d_off, d_len, 1, c.n_head, n, att_scale, st);
+      gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
+           first ? nullptr : x, d, n, false);
+      lnorm(m, st, x, d, m->y.f(), d, p + "norm2", n, d, d);
+      gemm(m, st, m->y.f(), d, m->W(p + "ffn1.w").d, c.ffn, d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0,
+           nullptr, 0, n, true);
+      gemm(m, st, m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, d, c.ffn, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0,
+           n, false);
+    }
+    lnorm(m, st, x, d, s->enc.f(), d, "enc.after_norm", n, d, d);
+    // predictor alphas: conv1d k=3 over the window (zero padded at its ends) -> relu -> linear -> sigmoid
     float* col = m->qkv.f();
     float* po = m->ctx.f();
     pfhip::launch_im2col3(s->enc.f(), d, col, 3 * d, dm + 16, dm + 16 + 128, n, d, st);
@@ -149,56 +186,57 @@ pfhip_status forward_chunk(pfhip_stream* s, int n, hipStream_t st, std::vector<i
          c.pred_residual ? s->enc.f() : nullptr, d, nullptr, 0, n, true);
     pfhip::launch_alpha(po, d, m->W("pred.out.w").d, m->W("pred.out.b").d, c.smooth_factor, c.noise_threshold,
                         s->alphas.f(), n, d, st);
-  }
-  // ---- CifSearch (:270-345) ---------------------------------------------------------------------------
-  pfhip::launch_cif_stream(s->enc.f(), d, s->alphas.f(), n, s->chunk_size[0], s->chunk_size[0] + s->chunk_size[1],
-                           s->is_last_chunk ? 1 : 0, c.cif_threshold, c.tail_threshold, s->carry.f(), s->carry.f() + d,
-                           s->emb.f(), s->nfire.i(), d, st);
-  HIP_TRY(hipMemcpyAsync(s->h_pin, s->nfire.p, 4, hipMemcpyDeviceToHost, st));
+    // ---- CifSearch (:270-345) ---------------------------------------------------------------------------
+    pfhip::launch_cif_stream(s->enc.f(), d, s->alphas.f(), n, s->chunk_size[0], s->chunk_size[0] + s->chunk_size[1], is_last,
+                             c.cif_threshold, c.tail_threshold, s->carry.f(), s->carry.f() + d, s->emb.f(), s->nfire.i(), d, st);
+    HIP_TRY(hipMemcpyAsync(s->h_pin, s->nfire.p, 4, hipMemcpyDeviceToHost, st));
+    return PFHIP_OK;
+  });
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(st));
   const int N = s->h_pin[0];
   s->last_fires = N;
   if (N <= 0) { HIP_TRY(hipGetLastError()); return PFHIP_OK; }          // :472 decoder only if CIF fired
   if (N > kMaxTok) return fail(PFHIP_ERR_CAPACITY, "more CIF fires in one chunk than the stream workspace holds");
-  {
-    int* hm = s->h_pin + 256;
-    hm[0] = N;
-    HIP_TRY(hipMemcpyAsync(d_tok, hm, 4, hipMemcpyHostToDevice, st));
-  }
+  s->h_pin[256] = N;       // tok_len staging (read by the copy below at execution time)
   // ---- streaming decoder session (:500): FSMN with the 10-frame cache, cross-attention over this window ----
   float* xd = m->xd.f();
-  HIP_TRY(hipMemcpyAsync(xd, s->emb.p, (size_t)N * d * 4, hipMemcpyDeviceToDevice, st));
   float* kvbuf = m->qkv.f();
-  auto dec_ffn = [&](const std::string& p, const float* xin, float* o) {
-    lnorm(m, st, xin, d, m->yd.f(), d, p + "norm1", N, d, d);
-    gemm(m, st, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
-         0, nullptr, 0, N, true);
-    lnorm(m, st, m->hd.f(), c.dec_ffn, m->hd2.f(), c.dec_ffn, p + "ffn_norm", N, c.dec_ffn, c.dec_ffn);
-    gemm(m, st, m->hd2.f(), c.dec_ffn, m->W(p + "ffn2.w").d, d, c.dec_ffn, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
-         N, false);
-  };
-  for (int i = 0; i < c.dec_layers; ++i) {
-    const std::string p = "dec." + std::to_string(i) + ".";
-    dec_ffn(p, xd, m->td.f());
-    lnorm(m, st, m->td.f(), d, m->t2.f(), d, p + "norm2", N, d, d);
-    pfhip::launch_fsmn_cached(m->t2.f(), m->W(p + "fsmn.w").d, xd, xd, s->dcache.f() + (size_t)i * 10 * d, N, d, st);
-    lnorm(m, st, xd, d, m->yd.f(), d, p + "norm3", N, d, d);
-    gemm(m, st, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, N, false);
-    gemm(m, st, s->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, n,
-         false);
-    pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_off, d_tok, d_off, d_len, 1,
-                            c.n_head, N, att_scale, st);
-    gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, N, false);
-  }
-  dec_ffn("dec3.", xd, m->td.f());
-  lnorm(m, st, m->td.f(), d, m->yd.f(), d, "dec.after_norm", N, d, d);
-  gemm(m, st, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
-       nullptr, 0, N, false);
-  if (want_logp) HIP_TRY(s->logp.ensure((size_t)128 * c.vocab * 4));
-  pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, N, c.vocab, want_logp ? s->logp.f() : nullptr,
-                                  static_cast<int32_t*>(s->ids.p), st);
+  rc = run_cached(s, 0x10000 | (N << 8) | n, graphs, st, [&]() -> pfhip_status {
+    HIP_TRY(hipMemcpyAsync(d_tok, s->h_pin + 256, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(xd, s->emb.p, (size_t)N * d * 4, hipMemcpyDeviceToDevice, st));
+    auto dec_ffn = [&](const std::string& p, const float* xin, float* o) {
+      lnorm(m, st, xin, d, m->yd.f(), d, p + "norm1", N, d, d);
+      gemm(m, st, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
+           0, nullptr, 0, N, true);
+      lnorm(m, st, m->hd.f(), c.dec_ffn, m->hd2.f(), c.dec_ffn, p + "ffn_norm", N, c.dec_ffn, c.dec_ffn);
+      gemm(m, st, m->hd2.f(), c.dec_ffn, m->W(p + "ffn2.w").d, d, c.dec_ffn, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
+           N, false);
+    };
+    for (int i = 0; i < c.dec_layers; ++i) {
+      const std::string p = "dec." + std::to_string(i) + ".";
+      dec_ffn(p, xd, m->td.f());
+      lnorm(m, st, m->td.f(), d, m->t2.f(), d, p + "norm2", N, d, d);
+      pfhip::launch_fsmn_cached(m->t2.f(), m->W(p + "fsmn.w").d, xd, xd, s->dcache.f() + (size_t)i * 10 * d, N, d, st);
+      lnorm(m, st, xd, d, m->yd.f(), d, p + "norm3", N, d, d);
+      gemm(m, st, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, N, false);
+      gemm(m, st, s->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, n,
+           false);
+      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_off, d_tok, d_off, d_len, 1,
+                              c.n_head, N, att_scale, st);
+      gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, N, false);
+    }
+    dec_ffn("dec3.", xd, m->td.f());
+    lnorm(m, st, m->td.f(), d, m->yd.f(), d, "dec.after_norm", N, d, d);
+    gemm(m, st, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
+         nullptr, 0, N, false);
+    pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, N, c.vocab, want_logp ? s->logp.f() : nullptr,
+                                    static_cast<int32_t*>(s->ids.p), st);
+    HIP_TRY(hipMemcpyAsync(s->h_pin + 1, s->ids.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    return PFHIP_OK;
+  });
+  if (rc) return rc;
   s->last_has_logp = want_logp;
-  HIP_TRY(hipMemcpyAsync(s->h_pin + 1, s->ids.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   for (int i = 0; i < N; ++i) out.push_back(s->h_pin[1 + i]);        // OnlineGreedySearch paraformer.cpp:362-371
@@ -355,6 +393,7 @@ void pfhip_stream_destroy(pfhip_stream* s) {
                    &s->nfire, &s->dcache, &s->meta, &s->ids, &s->logp})
       b->release();
     if (s->h_pin) (void)hipHostFree(s->h_pin);
+    drop_graphs(s);
   }
   delete s;
 }
@@ -447,7 +486,8 @@ pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_sampl
 
 pfhip_status pfhip_stream_set_debug(pfhip_stream* s, int on) {
   if (!s) return fail(PFHIP_ERR_ARG, "null stream");
-  s->debug = on != 0;
+  s->debug = (on & 1) != 0;          // bit 0: keep log-probs (disables graph replay); bit 1: never use hipGraphs
+  s->use_graphs = (on & 2) == 0;
   return PFHIP_OK;
 }
 

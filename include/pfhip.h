@@ -131,7 +131,8 @@ pfhip_status pfhip_stream_reset(pfhip_stream* s);
 pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_samples, int input_finished,
                                   int32_t* token_ids, int cap, int* n_tokens);
 /* Inspection of the LAST encoder window of the last call: "chunk" [n,560], "enc" [n,d], "alphas" [n],
- * "emb" [fires,d], "logp" [fires,vocab] (log-probs are only kept after pfhip_stream_set_debug(s,1)). */
+ * "emb" [fires,d], "logp" [fires,vocab] (log-probs are only kept after pfhip_stream_set_debug(s,1)).
+ * set_debug bits: 1 = keep log-probs (implies eager launches), 2 = never replay hipGraphs (eager launches). */
 pfhip_status pfhip_stream_set_debug(pfhip_stream* s, int on);
 pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* dst, size_t cap_floats,
                                      size_t* n_out);

@@ -95,3 +95,29 @@ def test_two_streams_do_not_interfere(small):
         assert hb.Forward(sb, input_finished=fin) == rb.Forward(sb, fin)
     ha.close()
     hb.close()
+
+
+def test_graph_replay_equals_eager(small):
+    """The hipGraph path (default) and the eager path (set_debug bit 1) must emit identical tokens, chunk by chunk,
+    incl. graph re-use across equal window shapes and the final first/last-chunk split."""
+    pkg, model, W = small
+    rng = np.random.default_rng(21)
+    pcm = synth_pcm(9, 9600 * 8 + 3000, rng)
+    g = pkg.ParaformerOnlineHip(model)
+    e = pkg.ParaformerOnlineHip(model)
+    e.set_debug(2)
+    ref = PO.ParaformerOnline(W)
+    steps = [(9600, False)] * 8 + [(3000, True)]
+    pos = 0
+    total = 0
+    for n, fin in steps:
+        seg = pcm[pos:pos + n]
+        pos += n
+        a = g.Forward(seg, input_finished=fin)
+        b = e.Forward(seg, input_finished=fin)
+        r = ref.Forward(seg, fin)
+        assert a == b == r
+        total += len(a)
+    assert total > 0
+    g.close()
+    e.close()

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
-    "pfhip_is_contextual", "pfhip_hotword_embed", "pfhip_set_hotwords",
+    "pfhip_set_batching", "pfhip_is_contextual", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
@@ -85,6 +85,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_offline_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
     lib.pfhip_extract_feats.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ctypes.c_size_t, vp]
     lib.pfhip_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.pfhip_set_batching.argtypes = [vp, ci, ci]
     lib.pfhip_is_contextual.argtypes = [vp]
     lib.pfhip_hotword_embed.argtypes = [vp, vp, vp, ci, vp]
     lib.pfhip_set_hotwords.argtypes = [vp, vp, ci]
@@ -189,6 +190,10 @@ class ParaformerHip:
 
     def GetBatchSize(self):
         return self._batch_size
+
+    def set_batching(self, wait_us, max_utterances=32):
+        """Merge concurrent Forward callers into one packed device batch (pfhip_set_batching)."""
+        _check(self._lib, self._lib.pfhip_set_batching(self._h, int(wait_us), int(max_utterances)))
 
     def StartUtterance(self):  # paraformer.cpp:297-307: stateless
         pass

@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -101,6 +103,8 @@ using pfhip_detail::Config;
 using pfhip_detail::ProfRec;
 using pfhip_detail::Tensor;
 
+struct BatchReq;
+
 struct pfhip_model {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -134,6 +138,13 @@ struct pfhip_model {
       *m_row_pos = nullptr, *m_row_len = nullptr;
   int64_t* m_sample_off = nullptr;
   int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr, *m_hw_off = nullptr, *m_hw_len = nullptr;
+
+  // cross-request batching (pfhip_set_batching): callers queue here, one of them leads a merged forward
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::deque<struct BatchReq*> queue;
+  bool leader_active = false;
+  int batch_wait_us = 0, batch_max_utts = 32;
 
   // profiling
   int prof_mask = 0;             // bit c set -> launches of kernel class c are bracketed by events

@@ -83,6 +83,12 @@ typedef struct {
 pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, const int* n_samples,
                                    int batch, const float* hw_emb, int n_hotwords, pfhip_out* out);
 
+/* Cross-request batching for the host-buffer form: with wait_us > 0, concurrent pfhip_offline_forward callers (the
+ * server's decoder threads, funasr-wss-server.cpp:479-481) are merged into one packed forward of up to max_utterances
+ * utterances; the first caller waits at most wait_us for others.  Results are identical to separate calls.
+ * 0 switches it off (default).  Contextual models are not merged (hotwords are per connection). */
+pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances);
+
 /* Device-resident form (what bench.py times): d_pcm is ONE device buffer holding the utterances
  * back to back; sample_off/n_samples are host arrays.  All kernels are enqueued on `stream`
  * (a hipStream_t, NULL = the model's own stream); results stay in the model's device workspace until

@@ -132,3 +132,37 @@ def test_full_size_properties(pkg, weights_mod):
     c = model.forward_ids(utts)
     assert all(list(x) == list(y) for x, y in zip(a["ids"], c["ids"]))
     model.close()
+
+
+def test_cross_request_batching_matches_separate_calls(small):
+    """pfhip_set_batching: concurrent callers (the server's decoder threads) are merged into one packed forward;
+    every caller must get exactly what a call on its own returns."""
+    import threading
+    model, _ = small
+    rng = np.random.default_rng(31)
+    reqs = [[synth_pcm(i * 3 + j, int(rng.integers(8000, 70000)), rng) for j in range(1 + i % 3)] for i in range(7)]
+    alone = [model.forward_ids(r, want_logp=(i % 2 == 0)) for i, r in enumerate(reqs)]
+    model.set_batching(20000, 16)
+    got = [None] * len(reqs)
+    errs = []
+
+    def work(i):
+        try:
+            got[i] = model.forward_ids(reqs[i], want_logp=(i % 2 == 0))
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(reqs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    model.set_batching(0, 32)
+    assert not errs, errs
+    for a, g in zip(alone, got):
+        assert list(a["token_num"]) == list(g["token_num"]) and list(a["n_frames"]) == list(g["n_frames"])
+        for x, y in zip(a["ids"], g["ids"]):
+            assert list(x) == list(y)
+        if a["logp"] is not None:
+            for x, y in zip(a["logp"], g["logp"]):
+                assert np.abs(x - y).max() < 1e-4

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ A, con
   acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc10, 0, 0, 0); acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc11, 0, 0, 0);
 #define M16(A0, A1, B0, B1) M4(A0, A1, B0, B1, x) M4(A0, A1, B0, B1, y) M4(A0, A1, B0, B1, z) M4(A0, A1, B0, B1, w)
 #define SB __builtin_amdgcn_sched_barrier(0)
-  if (V >= 33 && V < 40 && ((blockIdx.x >> 8) & 1)) { if (V == 33) __builtin_amdgcn_s_sleep(32); if (V == 34) __builtin_amdgcn_s_sleep(64); if (V == 35) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(64);} }
+  if ((V == 38 || V == 39 || V == 37) && ((blockIdx.x >> 8) & 1)) { const int reps = V == 37 ? 2 : (V == 38 ? 4 : 8); for (int q = 0; q < reps; ++q) __builtin_amdgcn_s_sleep(127); }
+  if (V >= 33 && V < 37 && ((blockIdx.x >> 8) & 1)) { if (V == 33) __builtin_amdgcn_s_sleep(32); if (V == 34) __builtin_amdgcn_s_sleep(64); if (V == 35) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(64);} }
   FRAG(fa0, fa1, fb0, fb1, 0, 0);
   ga0 = fa0; ga1 = fa1; gb0 = fb0; gb1 = fb1;
   for (int kt = 0; kt < nk; ++kt) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ A, con
   // minimal epilogue so nothing is dead: one float per lane
   float s = 0.f;
   for (int e = 0; e < 16; ++e) s += acc00[e] + acc01[e] + acc10[e] + acc11[e];
-  if (V < 4 || V >= 30) { C[(size_t)(m0 + wr * 64 + r) * ldc + n0 + wc * 64 + h] = s; return; }
+  if (V < 4 || (V >= 30 && V < 36)) { C[(size_t)(m0 + wr * 64 + r) * ldc + n0 + wc * 64 + h] = s; return; }
   __syncthreads();
   float* const Cs = lds; constexpr int kCs = 132;
   { float* cw = Cs + (wr * 64 + 4 * h) * kCs + wc * 64 + r;
@@ -252,6 +253,9 @@ int main() {
       float c = run<32>(A, W, C, R, M, N, K, 20); printf("V32 early sstore  %7.1f us %6.1f TF\n", c * 1e3, fl / c / 1e9);
       float d3 = run<33>(A, W, C, R, M, N, K, 20), d4 = run<34>(A, W, C, R, M, N, K, 20), d5 = run<35>(A, W, C, R, M, N, K, 20);
       printf("V33 +sleep32      %7.1f us %6.1f TF\nV34 +sleep64      %7.1f us %6.1f TF\nV35 +sleep128     %7.1f us %6.1f TF\n", d3 * 1e3, fl / d3 / 1e9, d4 * 1e3, fl / d4 / 1e9, d5 * 1e3, fl / d5 / 1e9); }
+    { float e6 = run<36>(A, W, C, R, M, N, K, 20), e7 = run<37>(A, W, C, R, M, N, K, 20), e8 = run<38>(A, W, C, R, M, N, K, 20), e9 = run<39>(A, W, C, R, M, N, K, 20);
+      printf("V36' early+epi     %7.1f us %6.1f TF\nV37 +stagger 7us   %7.1f us %6.1f TF\nV38 +stagger 14us  %7.1f us %6.1f TF\nV39 +stagger 28us  %7.1f us %6.1f TF\n",
+             e6 * 1e3, fl / e6 / 1e9, e7 * 1e3, fl / e7 / 1e9, e8 * 1e3, fl / e8 / 1e9, e9 * 1e3, fl / e9 / 1e9); }
     { float d = run_pf2(A, W, C, R, M, N, K, 20); printf("V36 prefetch dist 2 %7.1f us %6.1f TF\n", d * 1e3, fl / d / 1e9);
       std::vector<float> c1((size_t)128 * N), c2((size_t)128 * N);
       run<4>(A, W, C, R, M, N, K, 1); hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
     "pfhip_timestamp_onnx",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
+    "pfhip_punc_infer_online",
 ]
 
 
@@ -114,6 +115,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_punc_destroy.restype = None
     lib.pfhip_punc_num_classes.argtypes = [vp]
     lib.pfhip_punc_infer.argtypes = [vp, vp, ci, vp, vp]
+    lib.pfhip_punc_infer_online.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -459,14 +461,18 @@ class CTTransformerHip:
         except Exception:
             pass
 
-    def Infer(self, input_data, want_logits=False):
+    def Infer(self, input_data, want_logits=False, nCacheSize=None):
+        """nCacheSize=None: CTTransformer::Infer; an int: CTTransformerOnline::Infer(input_data, nCacheSize)."""
         ids = np.ascontiguousarray(input_data, dtype=np.int32)
         n = int(ids.size)
         punc = np.zeros(n, np.int32)
         C = self._lib.pfhip_punc_num_classes(self._h)
         logits = np.zeros((n, C), np.float32) if want_logits else None
-        _check(self._lib, self._lib.pfhip_punc_infer(self._h, ids.ctypes.data, n, punc.ctypes.data,
-                                                     logits.ctypes.data if want_logits else None))
+        lp = logits.ctypes.data if want_logits else None
+        if nCacheSize is None:
+            _check(self._lib, self._lib.pfhip_punc_infer(self._h, ids.ctypes.data, n, punc.ctypes.data, lp))
+        else:
+            _check(self._lib, self._lib.pfhip_punc_infer_online(self._h, ids.ctypes.data, n, int(nCacheSize), punc.ctypes.data, lp))
         return (punc, logits) if want_logits else punc
 
 

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
     const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
     const int* __restrict__ q_off, const int* __restrict__ q_len, const int* __restrict__ kv_off,
-    const int* __restrict__ kv_len, float scale) {
+    const int* __restrict__ kv_len, const int* __restrict__ q_kv_limit, float scale) {
   constexpr int kHeadDim = HD;
   constexpr int kKS = HD + 4;                        // padded K-tile row stride: conflict-free ds_read_b128
   constexpr int kKVBuf = kKT * kKS + kKT * HD;       // floats per (K,V) buffer
@@ -57,9 +57,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 
   // ---- Q slice of this lane: row q0 + wave*32 + r, d = 8*kb + 4*h + kk -------------------------
   float4 qreg[NKB];
+  int klim = Lk;              // keys this lane's query may see: all, or a per-query prefix (CT-Transformer VadMask)
   {
     int qrow = q0 + wave * kQW + r;
     if (qrow >= Lq) qrow = Lq - 1;
+    if (q_kv_limit) { const int l = q_kv_limit[qbase + qrow]; klim = l < Lk ? l : Lk; }
     const float* qp = Q + (qbase + qrow) * ldq + head * kHeadDim + 4 * h;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) qreg[kb] = *reinterpret_cast<const float4*>(qp + kb * 8);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = key0 + (e & 3) + 8 * (e >> 2);
-      const float sv = (key < Lk) ? sacc[e] * scale : -INFINITY;
+      const float sv = (key < klim) ? sacc[e] * scale : -INFINITY;
       sacc[e] = sv;
       tmax = fmaxf(tmax, sv);
     }
@@ -236,6 +238,19 @@ void launch_attention(const float* Q, int ldq, const float* K, int ldk, const fl
   launch_attention_hd(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, kHeadDim, s);
 }
 
+void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                             const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
+                             const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s) {
+  if (B <= 0 || max_q_len <= 0) return;
+  const dim3 grid((max_q_len + kQB - 1) / kQB, H, B), block(256);
+  if (head_dim == 32)
+    hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
+                       kv_len, q_kv_limit, scale);
+  else
+    hipLaunchKernelGGL(attention_kernel<128>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
+                       kv_len, q_kv_limit, scale);
+}
+
 void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                          int max_q_len, float scale, int head_dim, hipStream_t s) {
@@ -243,10 +258,10 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
   const dim3 grid((max_q_len + kQB - 1) / kQB, H, B), block(256);
   if (head_dim == 32)
     hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
-                       kv_len, scale);
+                       kv_len, static_cast<const int*>(nullptr), scale);
   else
     hipLaunchKernelGGL(attention_kernel<128>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
-                       kv_len, scale);
+                       kv_len, static_cast<const int*>(nullptr), scale);
 }
 
 }  // namespace pfhip

@@ -56,6 +56,10 @@ void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g
 // segment [off[b], off[b]+len[b]) with zero padding outside the segment.  C % 4 == 0, k == 11.
 void launch_fsmn(const float* v, int ldv, const float* w, const float* res, int ldres, float* out,
                  int ldo, const int* off, const int* len, int B, int max_len, int C, hipStream_t s);
+// Same with the window shifted into the past by `shift` frames (UPSTREAM sanm_shfit): taps cover
+// [t - 5 - shift, t + 5 - shift]; shift is 0 or 5 (5 = fully causal, the vad-realtime punctuation model).
+void launch_fsmn_shift(const float* v, int ldv, const float* w, const float* res, int ldres, float* out,
+                       int ldo, const int* off, const int* len, int B, int max_len, int C, int shift, hipStream_t s);
 
 // Multi-head attention, d_k = 128: O[q, h*128:(h+1)*128] = softmax(scale * Q_h K_h^T) V_h over the
 // utterance's own keys.  q segments (q_off,q_len), kv segments (kv_off,kv_len), all device arrays.
@@ -67,6 +71,12 @@ void launch_attention(const float* Q, int ldq, const float* K, int ldk, const fl
 void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                          int max_q_len, float scale, int head_dim, hipStream_t s);
+
+// With a per-query key limit: query row i (packed index) only sees keys [0, min(kv_len, q_kv_limit[i])) — the
+// prefix mask CTTransformerOnline::VadMask builds (ct-transformer-online.cpp:225-240).
+void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                             const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
+                             const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s);
 
 // ---- predictor / CIF (SURVEY §8a rows a4,a12) -------------------------------------------------
 // col[row] = [h[t-1] | h[t] | h[t+1]] with zeros outside the utterance.  row_pos/row_len give the

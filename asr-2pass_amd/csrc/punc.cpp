@@ -21,7 +21,7 @@ struct pfhip_punc {
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
-  int vocab = 0, d = 256, n_head = 8, ffn = 1024, layers = 4, n_punc = 6;
+  int vocab = 0, d = 256, n_head = 8, ffn = 1024, layers = 4, n_punc = 6, sanm_shift = 0;
   float* d_table = nullptr;
   float* d_inv_ts = nullptr;
   struct Layer { float *n1g, *n1b, *n2g, *n2b, *fsmn; Lin qkv, out, ffn1, ffn2; };
@@ -29,7 +29,7 @@ struct pfhip_punc {
   float *an_g = nullptr, *an_b = nullptr;
   Lin head;
   std::vector<float*> owned;
-  Buf ids, x, y, qkv, mem, ctx, h, logits, punc, meta;
+  Buf ids, x, y, qkv, mem, ctx, h, logits, punc, meta, lim;
   int* h_pin = nullptr;
 };
 
@@ -58,6 +58,8 @@ pfhip_status pfhip_punc_create_from_memory(const void* blob, size_t blob_bytes, 
   p->layers = (int)jc->number("layers", 4);
   p->n_punc = (int)jc->number("n_punc", 6);
   const int kernel = (int)jc->number("kernel", 11);
+  p->sanm_shift = (int)jc->number("sanm_shift", 0);
+  if (p->sanm_shift != 0 && p->sanm_shift != 5) return fail(PFHIP_ERR_UNSUPPORTED, "sanm_shift must be 0 or 5");
   const int d = p->d;
   if (p->vocab <= 0 || d % 128 || d > 512 || d / p->n_head != 32 || kernel != 11 || p->ffn % 128 || p->ffn > 2048 ||
       p->n_punc < 2 || p->n_punc > 128)
@@ -134,7 +136,7 @@ void pfhip_punc_destroy(pfhip_punc* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   (void)hipDeviceSynchronize();
-  for (Buf* b : {&p->ids, &p->x, &p->y, &p->qkv, &p->mem, &p->ctx, &p->h, &p->logits, &p->punc, &p->meta}) b->release();
+  for (Buf* b : {&p->ids, &p->x, &p->y, &p->qkv, &p->mem, &p->ctx, &p->h, &p->logits, &p->punc, &p->meta, &p->lim}) b->release();
   for (auto& l : p->L) { free_lin(l.qkv); free_lin(l.out); free_lin(l.ffn1); free_lin(l.ffn2); }
   free_lin(p->head);
   for (float* q : p->owned) (void)hipFree(q);
@@ -145,7 +147,18 @@ void pfhip_punc_destroy(pfhip_punc* p) {
 
 int pfhip_punc_num_classes(const pfhip_punc* p) { return p ? p->n_punc : 0; }
 
+static pfhip_status punc_infer_impl(pfhip_punc* p, const int32_t* ids, int n, int vad_pos, int32_t* punc_out, float* logits_out);
+
 pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, float* logits_out) {
+  return punc_infer_impl(p, ids, n, -1, punc_out, logits_out);
+}
+
+pfhip_status pfhip_punc_infer_online(pfhip_punc* p, const int32_t* ids, int n, int cache_size, int32_t* punc_out,
+                                     float* logits_out) {
+  return punc_infer_impl(p, ids, n, cache_size < 0 ? 0 : cache_size, punc_out, logits_out);
+}
+
+static pfhip_status punc_infer_impl(pfhip_punc* p, const int32_t* ids, int n, int vad_pos, int32_t* punc_out, float* logits_out) {
   last_error().clear();
   if (!p || !ids || n <= 0 || !punc_out) return fail(PFHIP_ERR_ARG, "bad argument");
   for (int i = 0; i < n; ++i)
@@ -168,6 +181,18 @@ pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t*
   HIP_TRY(hipMemcpyAsync(p->meta.p, p->h_pin, 8, hipMemcpyHostToDevice, s));
   const int* d_off = p->meta.i();
   const int* d_len = p->meta.i() + 1;
+  // CTTransformerOnline::VadMask (ct-transformer-online.cpp:225-240) as a per-query key limit: rows i < vad_pos-1 see
+  // keys [0, vad_pos), all other rows see everything; the reference feeds this ONE mask to both mask inputs (:182-197)
+  const int* d_lim = nullptr;
+  std::vector<int> lim;
+  if (vad_pos >= 0) {
+    HIP_TRY(p->lim.ensure((size_t)n * 4));
+    lim.assign(n, n);
+    if (vad_pos > 0 && vad_pos < n) for (int i = 0; i < vad_pos - 1; ++i) lim[i] = vad_pos;
+    HIP_TRY(hipMemcpyAsync(p->lim.p, lim.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    d_lim = p->lim.i();
+  }
   float* x = p->x.f();
   pfhip::launch_embed_gather(static_cast<const int32_t*>(p->ids.p), p->d_table, p->vocab, d, x, d, n, p->d_inv_ts,
                              sqrtf((float)d), s);
@@ -176,9 +201,10 @@ pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t*
     const pfhip_punc::Layer& l = p->L[i];
     pfhip::launch_layernorm(x, d, p->y.f(), d, l.n1g, l.n1b, n, d, d, 1e-12f, s);
     lin_gemm(s, l.qkv, p->y.f(), d, p->qkv.f(), 3 * d, nullptr, 0, nullptr, 0, n, false);
-    pfhip::launch_fsmn(p->qkv.f() + 2 * d, 3 * d, l.fsmn, nullptr, 0, p->mem.f(), d, d_off, d_len, 1, n, d, s);
-    pfhip::launch_attention_hd(p->qkv.f(), 3 * d, p->qkv.f() + d, 3 * d, p->qkv.f() + 2 * d, 3 * d, p->ctx.f(), d, d_off,
-                               d_len, d_off, d_len, 1, p->n_head, n, att_scale, 32, s);
+    pfhip::launch_fsmn_shift(p->qkv.f() + 2 * d, 3 * d, l.fsmn, nullptr, 0, p->mem.f(), d, d_off, d_len, 1, n, d,
+                             p->sanm_shift, s);
+    pfhip::launch_attention_masked(p->qkv.f(), 3 * d, p->qkv.f() + d, 3 * d, p->qkv.f() + 2 * d, 3 * d, p->ctx.f(), d, d_off,
+                                   d_len, d_off, d_len, d_lim, 1, p->n_head, n, att_scale, 32, s);
     lin_gemm(s, l.out, p->ctx.f(), d, x, d, p->mem.f(), d, x, d, n, false);          // in_size == size: residual
     pfhip::launch_layernorm(x, d, p->y.f(), d, l.n2g, l.n2b, n, d, d, 1e-12f, s);
     lin_gemm(s, l.ffn1, p->y.f(), d, p->h.f(), p->ffn, nullptr, 0, nullptr, 0, n, true);

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 constexpr int kFsmnK = 11;
 constexpr int kTT = 16;
 
+template <int LPAD>   // taps cover rows [t - LPAD, t + 10 - LPAD]
 __global__ __launch_bounds__(128) void fsmn_kernel(const float* __restrict__ v, int ldv,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ res, int ldres,
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(128) void fsmn_kernel(const float* __restrict__ v, 
 #pragma unroll
     for (int j = 0; j < kFsmnK; ++j) wk[ch][j] = w[(size_t)(c + ch) * kFsmnK + j];
 
-  constexpr int kHalf = (kFsmnK - 1) / 2;
+  constexpr int kHalf = LPAD;
   float4 win[kFsmnK];
   auto load_row = [&](int t) -> float4 {
     if (t < 0 || t >= L) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(128) void fsmn_kernel(const float* __restrict__ v, 
     // slide: win[j] <- win[j+1]; newest row enters at the end
 #pragma unroll
     for (int j = 0; j < kFsmnK - 1; ++j) win[j] = win[j + 1];
-    win[kFsmnK - 1] = load_row(t + kHalf);
+    win[kFsmnK - 1] = load_row(t + kFsmnK - 1 - kHalf);
     if (t < L) {
       float4 o = win[kHalf];
       if (res) {
@@ -288,7 +289,17 @@ void launch_fsmn(const float* v, int ldv, const float* w, const float* res, int 
                  int ldo, const int* off, const int* len, int B, int max_len, int C, hipStream_t s) {
   if (B <= 0 || max_len <= 0) return;
   const dim3 grid((max_len + kTT - 1) / kTT, B, (C + 511) / 512), block(128);
-  hipLaunchKernelGGL(fsmn_kernel, grid, block, 0, s, v, ldv, w, res, ldres, out, ldo, off, len, C);
+  hipLaunchKernelGGL(fsmn_kernel<5>, grid, block, 0, s, v, ldv, w, res, ldres, out, ldo, off, len, C);
+}
+
+void launch_fsmn_shift(const float* v, int ldv, const float* w, const float* res, int ldres, float* out, int ldo,
+                       const int* off, const int* len, int B, int max_len, int C, int shift, hipStream_t s) {
+  if (B <= 0 || max_len <= 0) return;
+  const dim3 grid((max_len + kTT - 1) / kTT, B, (C + 511) / 512), block(128);
+  if (shift == 5)
+    hipLaunchKernelGGL(fsmn_kernel<10>, grid, block, 0, s, v, ldv, w, res, ldres, out, ldo, off, len, C);
+  else
+    hipLaunchKernelGGL(fsmn_kernel<5>, grid, block, 0, s, v, ldv, w, res, ldres, out, ldo, off, len, C);
 }
 
 void launch_im2col3(const float* h, int ldh, float* col, int ldc, const int* row_pos,

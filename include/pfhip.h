@@ -197,6 +197,12 @@ pfhip_status pfhip_punc_create_from_memory(const void* blob, size_t blob_bytes, 
 void pfhip_punc_destroy(pfhip_punc* p);
 int pfhip_punc_num_classes(const pfhip_punc* p);
 pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, float* logits_out);
+/* Realtime variant <-> CTTransformerOnline::Infer(input_data, nCacheSize) (ct-transformer-online.cpp:154-223): the
+ * VadMask of :225-240 (queries before cache_size-1 do not see tokens from cache_size on) is applied in every attention
+ * block, because the reference feeds that one mask to both `vad_mask` and `sub_masks` (:182-197).  The model's FSMN
+ * look-ahead is the container's `sanm_shift` (0 or 5). */
+pfhip_status pfhip_punc_infer_online(pfhip_punc* p, const int32_t* ids, int n, int cache_size, int32_t* punc_out,
+                                     float* logits_out);
 
 /* ---- inspection (parity tests) -----------------------------------------------------------------
  * Copies a named intermediate of the LAST forward to host: "feats" [M,560], "enc" [M,d],

@@ -36,3 +36,60 @@ def infer(ids, W):
     logits = forward(ids, W)
     punc = np.argmax(logits[:, :W.cfg["n_punc"] - 1], axis=-1).astype(np.int32)
     return logits, punc
+
+
+def vad_mask(n, vad_pos):
+    """CTTransformerOnline::VadMask (ct-transformer-online.cpp:225-240)."""
+    m = np.ones((n, n), F32)
+    if vad_pos <= 0 or vad_pos >= n:
+        return m
+    m[:vad_pos - 1, vad_pos:] = 0.0
+    return m
+
+
+def fsmn_shift(v, w, shift):
+    """Depthwise conv with left padding (k-1)/2 + shift and right padding (k-1)/2 - shift (UPSTREAM sanm_shfit)."""
+    T, d = v.shape
+    k = w.shape[1]
+    lp = (k - 1) // 2 + shift
+    vp = np.zeros((T + k - 1, d), F32)
+    vp[lp:lp + T] = v
+    out = v.astype(F32).copy()
+    for j in range(k):
+        out += vp[j:j + T] * w[:, j][None, :]
+    return out.astype(F32)
+
+
+def mha_masked(q, k, v, n_head, mask):
+    Lq, d = q.shape
+    dk = d // n_head
+    out = np.empty((Lq, d), F32)
+    for h in range(n_head):
+        sl = slice(h * dk, (h + 1) * dk)
+        s = ((q[:, sl] * F32(dk ** -0.5)).astype(F32) @ k[:, sl].T).astype(F32)
+        s = np.where(mask > 0, s, F32(-np.inf))
+        out[:, sl] = P.softmax_rows(s) @ v[:, sl]
+    return out
+
+
+def forward_online(ids, W, vad_pos):
+    cfg = W.cfg
+    d = cfg["d_model"]
+    n = len(ids)
+    mask = vad_mask(n, vad_pos)            # one mask for both mask inputs (ct-transformer-online.cpp:182-197)
+    x = W["embed.w"][np.asarray(ids, np.int64)].astype(F32)
+    x = (x * F32(math.sqrt(d)) + fe.pos_emb(n, d)).astype(F32)
+    for i in range(cfg["layers"]):
+        pfx = f"enc.{i}."
+        y = P.layer_norm(x, W[pfx + "norm1.g"], W[pfx + "norm1.b"])
+        qkv = P.linear(y, W[pfx + "qkv.w"], W[pfx + "qkv.b"])
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        mem = fsmn_shift(v, W[pfx + "fsmn.w"], cfg.get("sanm_shift", 0))
+        att = P.linear(mha_masked(q, k, v, cfg["n_head"], mask), W[pfx + "out.w"], W[pfx + "out.b"]) + mem
+        x = (x + att).astype(F32)
+        y = P.layer_norm(x, W[pfx + "norm2.g"], W[pfx + "norm2.b"])
+        h = np.maximum(P.linear(y, W[pfx + "ffn1.w"], W[pfx + "ffn1.b"]), F32(0))
+        x = (x + P.linear(h, W[pfx + "ffn2.w"], W[pfx + "ffn2.b"])).astype(F32)
+    x = P.layer_norm(x, W["enc.after_norm.g"], W["enc.after_norm.b"])
+    logits = P.linear(x, W["out.w"], W["out.b"])
+    return logits, np.argmax(logits[:, :cfg["n_punc"] - 1], axis=-1).astype(np.int32)

@@ -56,3 +56,25 @@ def test_attention_head_dim_32_op(pkg):
     for b, (o, L) in enumerate(zip(off, lens)):
         ref = P.mha(Q[o:o + L].astype(np.float64), K[o:o + L].astype(np.float64), V[o:o + L].astype(np.float64), H)
         assert np.abs(O[o:o + L] - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("shift", [0, 5])
+def test_online_variant_with_vad_mask(pkg, weights_mod, shift):
+    """CTTransformerOnline::Infer: the VadMask prefix mask in every attention block + the shifted FSMN window."""
+    cfg = dict(weights_mod.CT_TRANSFORMER, vocab=3000, sanm_shift=shift)
+    man, blob = weights_mod.synth_punc_weights(cfg, seed=7 + shift)
+    h = pkg.CTTransformerHip().InitPunc((man, blob))
+    W = P.Weights(man, blob)
+    rng = np.random.default_rng(40 + shift)
+    for n, pos in [(30, 12), (30, 0), (30, 30), (75, 2), (140, 100)]:
+        ids = rng.integers(0, 3000, n).astype(np.int32)
+        gp, gl = h.Infer(ids, want_logits=True, nCacheSize=pos)
+        rl, rp = C.forward_online(ids, W, pos)
+        assert np.abs(gl - rl).max() < 1e-3, (n, pos)
+        assert np.array_equal(gp, rp)
+    # the mask matters: with a cut in the middle the early tokens' scores differ from the unmasked run
+    ids = rng.integers(0, 3000, 60).astype(np.int32)
+    _, a = h.Infer(ids, want_logits=True, nCacheSize=30)
+    _, b = h.Infer(ids, want_logits=True, nCacheSize=0)
+    assert np.abs(a[:20] - b[:20]).max() > 1e-3
+    h.close()

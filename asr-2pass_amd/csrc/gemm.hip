@@ -9,7 +9,8 @@
 // accumulators per lane).  K-step 32.  Both operands are K-contiguous (activations [M][K], weights
 // torch-style [N][K]), staged global -> registers -> LDS with a 36-float row stride (144 B = 9 slots
 // of 16 B, so the 16-lane groups of ds_read_b128 hit 16 distinct slots: conflict-free), two LDS
-// buffers, next tile's global loads in flight under the current tile's 64 MFMAs per wave.
+// buffers, next tile's global loads in flight under the current tile's 64 MFMAs per wave, every memory
+// instruction issued singly between two MFMAs (see the loop).
 // A lane reads 4 consecutive k of its row with one ds_read_b128; lane half h takes k = 8*kb+4*h+kk
 // at MFMA step kk, for A and B alike, so the k permutation cancels.
 //
@@ -60,98 +61,113 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
 
   // staging registers are named scalars (not arrays captured by lambdas): hipcc keeps them in VGPRs
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define PFHIP_GLOAD(k0)                                                               \
-  do {                                                                                \
-    ra0 = *reinterpret_cast<const float4*>(Ag + (k0));                                \
-    ra1 = *reinterpret_cast<const float4*>(Ag + (size_t)32 * lda + (k0));             \
-    ra2 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * lda + (k0));             \
-    ra3 = *reinterpret_cast<const float4*>(Ag + (size_t)96 * lda + (k0));             \
-    rb0 = *reinterpret_cast<const float4*>(Wg + (k0));                                \
-    rb1 = *reinterpret_cast<const float4*>(Wg + (size_t)32 * ldw + (k0));             \
-    rb2 = *reinterpret_cast<const float4*>(Wg + (size_t)64 * ldw + (k0));             \
-    rb3 = *reinterpret_cast<const float4*>(Wg + (size_t)96 * ldw + (k0));             \
-  } while (0)
-#define PFHIP_SSTORE(buf)                                                             \
-  do {                                                                                \
-    float* as_ = As + (buf) * kStage + lrow * kLds + 4 * lc4;                         \
-    float* bs_ = Bs + (buf) * kStage + lrow * kLds + 4 * lc4;                         \
-    *reinterpret_cast<float4*>(as_) = ra0;                                            \
-    *reinterpret_cast<float4*>(as_ + 32 * kLds) = ra1;                                \
-    *reinterpret_cast<float4*>(as_ + 64 * kLds) = ra2;                                \
-    *reinterpret_cast<float4*>(as_ + 96 * kLds) = ra3;                                \
-    *reinterpret_cast<float4*>(bs_) = rb0;                                            \
-    *reinterpret_cast<float4*>(bs_ + 32 * kLds) = rb1;                                \
-    *reinterpret_cast<float4*>(bs_ + 64 * kLds) = rb2;                                \
-    *reinterpret_cast<float4*>(bs_ + 96 * kLds) = rb3;                                \
-  } while (0)
+  float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;          // operand fragments: even k-blocks in f, odd in g
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_GL(reg, base, ld, j, k0) reg = *reinterpret_cast<const float4*>(base + (size_t)(32 * (j)) * ld + (k0))
+#define PFHIP_SW(reg, base, buf, j) \
+  *reinterpret_cast<float4*>(base + (buf) * kStage + lrow * kLds + 4 * lc4 + 32 * (j) * kLds) = reg
+#define PFHIP_FR(reg, base, off, buf, kb, j) \
+  reg = *reinterpret_cast<const float4*>(base + (buf) * kStage + off + (kb) * 8 + 32 * (j) * kLds)
+#define PFHIP_MM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
 
   const int nk = K / kTileK;
-  PFHIP_GLOAD(0);
-  PFHIP_SSTORE(0);
+  PFHIP_GL(ra0, Ag, lda, 0, 0); PFHIP_GL(ra1, Ag, lda, 1, 0); PFHIP_GL(ra2, Ag, lda, 2, 0); PFHIP_GL(ra3, Ag, lda, 3, 0);
+  PFHIP_GL(rb0, Wg, ldw, 0, 0); PFHIP_GL(rb1, Wg, ldw, 1, 0); PFHIP_GL(rb2, Wg, ldw, 2, 0); PFHIP_GL(rb3, Wg, ldw, 3, 0);
+  PFHIP_SW(ra0, As, 0, 0); PFHIP_SW(ra1, As, 0, 1); PFHIP_SW(ra2, As, 0, 2); PFHIP_SW(ra3, As, 0, 3);
+  PFHIP_SW(rb0, Bs, 0, 0); PFHIP_SW(rb1, Bs, 0, 1); PFHIP_SW(rb2, Bs, 0, 2); PFHIP_SW(rb3, Bs, 0, 3);
   __syncthreads();
 
   const int a_off = (wr * 64 + r) * kLds + 4 * h;
   const int b_off = (wc * 64 + r) * kLds + 4 * h;
+  PFHIP_FR(fa0, As, a_off, 0, 0, 0); PFHIP_FR(fa1, As, a_off, 0, 0, 1);
+  PFHIP_FR(fb0, Bs, b_off, 0, 0, 0); PFHIP_FR(fb1, Bs, b_off, 0, 0, 1);
 
-  // Software pipeline (one barrier per K-tile, never an empty matrix pipe around it):
-  //   top      : global loads of tile kt+1 go out (in flight under 48 MFMAs)
-  //   kb 0..2  : ds_read fragments of k-block kb+1 | 16 MFMAs of k-block kb
-  //              (before the MFMAs of k-block 2: ds_write tile kt+1 into the other buffer)
-  //   then     : barrier -> ds_read k-block 0 of tile kt+1 | 16 MFMAs of k-block 3
-  float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
-#define PFHIP_FRAG_LOAD(A0, A1, B0, B1, buf, kb)                                              \
-  do {                                                                                        \
-    const float* as_ = As + (buf) * kStage + a_off + (kb) * 8;                                \
-    const float* bs_ = Bs + (buf) * kStage + b_off + (kb) * 8;                                \
-    A0 = *reinterpret_cast<const float4*>(as_);                                               \
-    A1 = *reinterpret_cast<const float4*>(as_ + 32 * kLds);                                   \
-    B0 = *reinterpret_cast<const float4*>(bs_);                                               \
-    B1 = *reinterpret_cast<const float4*>(bs_ + 32 * kLds);                                   \
-  } while (0)
-#define PFHIP_MFMA4(A0, A1, B0, B1, c)                                                \
-  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc00, 0, 0, 0);           \
-  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B1.c, acc01, 0, 0, 0);           \
-  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc10, 0, 0, 0);           \
-  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc11, 0, 0, 0);
-#define PFHIP_MFMA16(A0, A1, B0, B1) \
-  PFHIP_MFMA4(A0, A1, B0, B1, x) PFHIP_MFMA4(A0, A1, B0, B1, y) PFHIP_MFMA4(A0, A1, B0, B1, z) PFHIP_MFMA4(A0, A1, B0, B1, w)
-
-  PFHIP_FRAG_LOAD(fa0, fa1, fb0, fb1, 0, 0);
+  // Software pipeline, one barrier per K-tile.  Per wave a K-tile is 64 MFMAs (4 k-blocks x 16) plus 8 global loads
+  // (next tile), 16 ds_read_b128 (fragments of the next k-block) and 8 ds_write_b128 (next tile into the other buffer).
+  // The memory instructions are issued ONE AT A TIME between single MFMAs, every statement pinned by a scheduling
+  // barrier: issued in bursts between groups of 16 MFMAs (the obvious layout) the same kernel is 15 % slower — each
+  // ds_read/global_load holds the wave's issue port long enough that a burst of 4-8 lets the matrix pipe run dry.
+  // The body below is generated (tools/probe/gen_gemm_loop.py, schedule "A"; tools/probe/gemm_sched.hip compares
+  // schedules): k-block 0 | global loads, reads of k-block 1;  k-block 1 | reads of k-block 2;  k-block 2 | reads of
+  // k-block 3, LDS writes, barrier;  k-block 3 | reads of k-block 0 of the next tile.
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     // unconditional (the last iteration re-fetches its own tile): keeps the loop body straight-line
     const int knext = (kt + 1 < nk ? kt + 1 : kt) * kTileK;
-    PFHIP_GLOAD(knext);
-    __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the loads to just above their ds_write
-    PFHIP_FRAG_LOAD(ga0, ga1, gb0, gb1, cur, 1);
-    __builtin_amdgcn_sched_barrier(0);   // fragment reads first, then the MFMAs that hide their latency
-    PFHIP_MFMA16(fa0, fa1, fb0, fb1)
-    __builtin_amdgcn_sched_barrier(0);
-    PFHIP_FRAG_LOAD(fa0, fa1, fb0, fb1, cur, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    PFHIP_MFMA16(ga0, ga1, gb0, gb1)
-    __builtin_amdgcn_sched_barrier(0);
-    PFHIP_FRAG_LOAD(ga0, ga1, gb0, gb1, cur, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    PFHIP_SSTORE(cur ^ 1);               // the other buffer: its ds_writes drain under the next 16 MFMAs
-    __builtin_amdgcn_sched_barrier(0);   // (measured +4 % over writing right in front of the barrier)
-    PFHIP_MFMA16(fa0, fa1, fb0, fb1)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    PFHIP_FRAG_LOAD(fa0, fa1, fb0, fb1, cur ^ 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    PFHIP_MFMA16(ga0, ga1, gb0, gb1)
-    __builtin_amdgcn_sched_barrier(0);
+    PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_GL(ra1, Ag, lda, 1, knext); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_GL(ra2, Ag, lda, 2, knext); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_GL(ra3, Ag, lda, 3, knext); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_GL(rb0, Wg, ldw, 0, knext); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_GL(rb1, Wg, ldw, 1, knext); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_GL(rb2, Wg, ldw, 2, knext); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_GL(rb3, Wg, ldw, 3, knext); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_FR(ga0, As, a_off, cur, 1, 0); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_FR(ga1, As, a_off, cur, 1, 1); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, cur, 1, 0); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, cur, 1, 1); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, cur, 2, 0); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, cur, 2, 1); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, cur, 2, 0); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, cur, 2, 1); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_FR(ga0, As, a_off, cur, 3, 0); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_FR(ga1, As, a_off, cur, 3, 1); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, cur, 3, 0); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, cur, 3, 1); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_SW(ra0, As, cur ^ 1, 0); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_SW(ra1, As, cur ^ 1, 1); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_SW(ra2, As, cur ^ 1, 2); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_SW(ra3, As, cur ^ 1, 3); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_SW(rb0, Bs, cur ^ 1, 0); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_SW(rb1, Bs, cur ^ 1, 1); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_SW(rb2, Bs, cur ^ 1, 2); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_SW(rb3, Bs, cur ^ 1, 3); PFHIP_SB;
+    PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB;
+    PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB;
+    PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB;
+    PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; __syncthreads();
+    PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, cur ^ 1, 0, 0); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, cur ^ 1, 0, 1); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, cur ^ 1, 0, 0); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, cur ^ 1, 0, 1); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB;
+    PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB;
+    PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB;
+    PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB;
+    PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB;
   }
-#undef PFHIP_FRAG_LOAD
-#undef PFHIP_MFMA4
-#undef PFHIP_MFMA16
-#undef PFHIP_GLOAD
-#undef PFHIP_SSTORE
+#undef PFHIP_SB
+#undef PFHIP_GL
+#undef PFHIP_SW
+#undef PFHIP_FR
+#undef PFHIP_MM
 
   // ---- epilogue: accumulators -> LDS (C/D map: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)) ----
   __syncthreads();                        // every wave has finished reading operand fragments

@@ -74,34 +74,23 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   rk1 = rk2 = rk3 = rv1 = rv2 = rv3 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Kh = K + kbase * ldk + head * kHeadDim + 4 * lc4;
   const float* Vh = V + kbase * ldv + head * kHeadDim + 4 * lc4;
-#define PFHIP_KV_LOAD1(RK, RV, i, kt)                                                   \
+  // one row group (RPP keys) of the next K or V tile -> staging registers / staging registers -> LDS
+#define PFHIP_K_LOAD(RK, i, kt)                                                         \
   do {                                                                                  \
     int key_ = (kt) * kKT + lrow + RPP * (i);                                           \
     key_ = key_ < Lk ? key_ : Lk - 1;                                                   \
     RK = *reinterpret_cast<const float4*>(Kh + (size_t)key_ * ldk);                     \
+  } while (0)
+#define PFHIP_V_LOAD(RV, i, kt)                                                         \
+  do {                                                                                  \
+    int key_ = (kt) * kKT + lrow + RPP * (i);                                           \
+    key_ = key_ < Lk ? key_ : Lk - 1;                                                   \
     RV = *reinterpret_cast<const float4*>(Vh + (size_t)key_ * ldv);                     \
   } while (0)
-#define PFHIP_KV_LOAD(kt)                                                               \
-  do {                                                                                  \
-    PFHIP_KV_LOAD1(rk0, rv0, 0, kt);                                                    \
-    if (NP > 1) { PFHIP_KV_LOAD1(rk1, rv1, 1, kt); PFHIP_KV_LOAD1(rk2, rv2, 2, kt);     \
-                  PFHIP_KV_LOAD1(rk3, rv3, 3, kt); }                                    \
-  } while (0)
-#define PFHIP_KV_STORE(buf)                                                             \
-  do {                                                                                  \
-    float* ks_ = lds + (buf) * kKVBuf + lrow * kKS + 4 * lc4;                           \
-    float* vs_ = lds + (buf) * kKVBuf + kKT * kKS + lrow * kHeadDim + 4 * lc4;          \
-    *reinterpret_cast<float4*>(ks_) = rk0;                                              \
-    *reinterpret_cast<float4*>(vs_) = rv0;                                              \
-    if (NP > 1) {                                                                       \
-      *reinterpret_cast<float4*>(ks_ + 8 * kKS) = rk1;                                  \
-      *reinterpret_cast<float4*>(ks_ + 16 * kKS) = rk2;                                 \
-      *reinterpret_cast<float4*>(ks_ + 24 * kKS) = rk3;                                 \
-      *reinterpret_cast<float4*>(vs_ + 8 * kHeadDim) = rv1;                             \
-      *reinterpret_cast<float4*>(vs_ + 16 * kHeadDim) = rv2;                            \
-      *reinterpret_cast<float4*>(vs_ + 24 * kHeadDim) = rv3;                            \
-    }                                                                                   \
-  } while (0)
+#define PFHIP_K_STORE(RK, i, buf) \
+  *reinterpret_cast<float4*>(lds + (buf) * kKVBuf + (lrow + RPP * (i)) * kKS + 4 * lc4) = RK
+#define PFHIP_V_STORE(RV, i, buf) \
+  *reinterpret_cast<float4*>(lds + (buf) * kKVBuf + kKT * kKS + (lrow + RPP * (i)) * kHeadDim + 4 * lc4) = RV
 
   f32x16 oacc0, oacc1, oacc2, oacc3;
 #pragma unroll
@@ -109,32 +98,52 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   float m_run = -1e30f, l_run = 0.f;
 
   const int nkt = (Lk + kKT - 1) / kKT;
-  PFHIP_KV_LOAD(0);
-  PFHIP_KV_STORE(0);
+  PFHIP_K_LOAD(rk0, 0, 0); PFHIP_V_LOAD(rv0, 0, 0);
+  if (NP > 1) {
+    PFHIP_K_LOAD(rk1, 1, 0); PFHIP_V_LOAD(rv1, 1, 0); PFHIP_K_LOAD(rk2, 2, 0); PFHIP_V_LOAD(rv2, 2, 0);
+    PFHIP_K_LOAD(rk3, 3, 0); PFHIP_V_LOAD(rv3, 3, 0);
+  }
+  PFHIP_K_STORE(rk0, 0, 0); PFHIP_V_STORE(rv0, 0, 0);
+  if (NP > 1) {
+    PFHIP_K_STORE(rk1, 1, 0); PFHIP_V_STORE(rv1, 1, 0); PFHIP_K_STORE(rk2, 2, 0); PFHIP_V_STORE(rv2, 2, 0);
+    PFHIP_K_STORE(rk3, 3, 0); PFHIP_V_STORE(rv3, 3, 0);
+  }
   __syncthreads();
 
+  // Memory instructions are issued singly between MFMA groups (the next tile's 2*NP global loads under the QK^T
+  // MFMAs, its 2*NP LDS writes under the PV MFMAs): in bursts they starve the matrix pipe (see gemm.hip).
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     // unconditional prefetch of the next tile (the last iteration re-fetches its own): straight-line body
-    PFHIP_KV_LOAD(kt + 1 < nkt ? kt + 1 : kt);
-    __builtin_amdgcn_sched_barrier(0);
+    const int ktn = kt + 1 < nkt ? kt + 1 : kt;
     const float* ks = lds + cur * kKVBuf;
     const float* vs = ks + kKT * kKS;
 
-    // S^T[key][q] = sum_d K[key][d] * Q[q][d]; the K fragment of k-block kb+1 is read under the 4 MFMAs of kb
-    f32x16 sacc;
+    // S^T[key][q] = sum_d K[key][d] * Q[q][d]; the K fragment of k-block kb+1 is read under the 4 MFMAs of kb.
+    // Two accumulators, alternated, so consecutive MFMAs never wait for each other's result.
+    f32x16 sacc, sacb;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; sacb[e] = 0.f; }
     const float* kp = ks + r * kKS + 4 * h;
     float4 ka = *reinterpret_cast<const float4*>(kp);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       const float4 kn = *reinterpret_cast<const float4*>(kp + (kb < NKB - 1 ? kb + 1 : kb) * 8);
+      if (kb == 0) PFHIP_K_LOAD(rk0, 0, ktn);
+      if (kb == 1) PFHIP_V_LOAD(rv0, 0, ktn);
+      if (NP > 1) {
+        if (kb == 2) PFHIP_K_LOAD(rk1, 1, ktn);
+        if (kb == 3) PFHIP_V_LOAD(rv1, 1, ktn);
+        if (kb == 4) PFHIP_K_LOAD(rk2, 2, ktn);
+        if (kb == 5) PFHIP_V_LOAD(rv2, 2, ktn);
+        if (kb == 6) PFHIP_K_LOAD(rk3, 3, ktn);
+        if (kb == 7) PFHIP_V_LOAD(rv3, 3, ktn);
+      }
       __builtin_amdgcn_sched_barrier(0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qreg[kb].x, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qreg[kb].y, sacc, 0, 0, 0);
+      sacb = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qreg[kb].y, sacb, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qreg[kb].z, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qreg[kb].w, sacc, 0, 0, 0);
+      sacb = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qreg[kb].w, sacb, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       ka = kn;
     }
@@ -145,17 +154,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = key0 + (e & 3) + 8 * (e >> 2);
-      const float sv = (key < klim) ? sacc[e] * scale : -INFINITY;
+      const float sv = (key < klim) ? (sacc[e] + sacb[e]) * scale : -INFINITY;
       sacc[e] = sv;
       tmax = fmaxf(tmax, sv);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
+    // __expf = v_exp_f32(x * log2 e), ~1 ulp: the library expf costs 10 more VALU ops per score (measured -7 %)
+    const float alpha = __expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = expf(sacc[e] - m_new);
+      const float pv = __expf(sacc[e] - m_new);
       sacc[e] = pv;
       psum += pv;
     }
@@ -181,6 +191,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       const float vn0 = vrow[0];
       float vn1 = 0.f, vn2 = 0.f, vn3 = 0.f;
       if (ND > 1) { vn1 = vrow[32]; vn2 = vrow[64]; vn3 = vrow[96]; }
+      if (e == 0) PFHIP_K_STORE(rk0, 0, cur ^ 1);
+      if (e == 1) PFHIP_V_STORE(rv0, 0, cur ^ 1);
+      if (NP > 1) {
+        if (e == 2) PFHIP_K_STORE(rk1, 1, cur ^ 1);
+        if (e == 3) PFHIP_V_STORE(rv1, 1, cur ^ 1);
+        if (e == 4) PFHIP_K_STORE(rk2, 2, cur ^ 1);
+        if (e == 5) PFHIP_V_STORE(rv2, 2, cur ^ 1);
+        if (e == 6) PFHIP_K_STORE(rk3, 3, cur ^ 1);
+        if (e == 7) PFHIP_V_STORE(rv3, 3, cur ^ 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const float pb = sacc[e];
       oacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, pb, oacc0, 0, 0, 0);
@@ -192,13 +212,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       __builtin_amdgcn_sched_barrier(0);
       va0 = vn0; va1 = vn1; va2 = vn2; va3 = vn3;
     }
-
-    PFHIP_KV_STORE(cur ^ 1);
     __syncthreads();
   }
-#undef PFHIP_KV_LOAD1
-#undef PFHIP_KV_LOAD
-#undef PFHIP_KV_STORE
+#undef PFHIP_K_LOAD
+#undef PFHIP_V_LOAD
+#undef PFHIP_K_STORE
+#undef PFHIP_V_STORE
 
   // ---- normalise, transpose through LDS, store full rows ------------------------------------------
   const float inv_l = 1.0f / l_run;

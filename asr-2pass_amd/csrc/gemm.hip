@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   const float* Ag = A + (size_t)(m0 + lrow) * lda + 4 * lc4;
   const float* Wg = W + (size_t)(n0 + lrow) * ldw + 4 * lc4;
 
-  // staging registers are named scalars (not arrays captured by lambdas): hipcc keeps them in VGPRs
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  // staging registers are named scalars (not arrays captured by lambdas): hipcc keeps them in VGPRs.
+  // Two sets (r*, s*): the global loads run two K-tiles ahead of the MFMAs.
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
   float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;          // operand fragments: even k-blocks in f, odd in g
 #define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
 #define PFHIP_GL(reg, base, ld, j, k0) reg = *reinterpret_cast<const float4*>(base + (size_t)(32 * (j)) * ld + (k0))
@@ -70,15 +71,162 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   reg = *reinterpret_cast<const float4*>(base + (buf) * kStage + off + (kb) * 8 + 32 * (j) * kLds)
 #define PFHIP_MM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
+  // Software pipeline, one barrier per K-tile.  Per wave a K-tile is 64 MFMAs (4 k-blocks x 16) plus 8 global loads
+  // (the tile two ahead), 16 ds_read_b128 (fragments of the next k-block) and 8 ds_write_b128 (the next tile, loaded
+  // one iteration earlier, into the other LDS buffer).  The memory instructions are issued ONE AT A TIME between
+  // single MFMAs, every statement pinned by a scheduling barrier: issued in bursts between groups of 16 MFMAs (the
+  // obvious layout) the same kernel is 15 % slower — each ds_read/global_load holds the wave's issue port long enough
+  // that a burst of 4-8 lets the matrix pipe run dry.  Prefetch distance 2 is worth +5 % at K = 2048 and nothing at
+  // K = 512.  The two bodies are generated (tools/probe/gen_gemm_loop.py, schedule "G"; tools/probe/gemm_sched.hip
+  // compares schedules): _0 computes from LDS buffer 0 (even K-tiles), loads into r*, stores s*; _1 the mirror image.
+  //   k-block 0 | global loads, reads of k-block 1;  k-block 1 | reads of k-block 2;
+  //   k-block 2 | reads of k-block 3, LDS writes, barrier;  k-block 3 | reads of k-block 0 of the next tile.
+#define PFHIP_BODY_0 \
+  PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_GL(ra1, Ag, lda, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_GL(ra2, Ag, lda, 2, knext); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_GL(ra3, Ag, lda, 3, knext); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_GL(rb0, Wg, ldw, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_GL(rb1, Wg, ldw, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_GL(rb2, Wg, ldw, 2, knext); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_GL(rb3, Wg, ldw, 3, knext); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_FR(ga0, As, a_off, 0, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_FR(ga1, As, a_off, 0, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, 0, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, 0, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 0, 2, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 0, 2, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 0, 2, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 0, 2, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_FR(ga0, As, a_off, 0, 3, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_FR(ga1, As, a_off, 0, 3, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, 0, 3, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, 0, 3, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_SW(sa0, As, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_SW(sa1, As, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_SW(sa2, As, 1, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_SW(sa3, As, 1, 3); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_SW(sb0, Bs, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_SW(sb1, Bs, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_SW(sb2, Bs, 1, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_SW(sb3, Bs, 1, 3); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; __syncthreads(); \
+  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 1, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 1, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 1, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 1, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB;
+#define PFHIP_BODY_1 \
+  PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_GL(sa0, Ag, lda, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_GL(sa1, Ag, lda, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_GL(sa2, Ag, lda, 2, knext); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_GL(sa3, Ag, lda, 3, knext); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_GL(sb0, Wg, ldw, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_GL(sb1, Wg, ldw, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_GL(sb2, Wg, ldw, 2, knext); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_GL(sb3, Wg, ldw, 3, knext); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_FR(ga0, As, a_off, 1, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_FR(ga1, As, a_off, 1, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, 1, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, 1, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 1, 2, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 1, 2, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 1, 2, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 1, 2, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_FR(ga0, As, a_off, 1, 3, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_FR(ga1, As, a_off, 1, 3, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, 1, 3, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, 1, 3, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_SW(ra0, As, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_SW(ra1, As, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_SW(ra2, As, 0, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_SW(ra3, As, 0, 3); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_SW(rb0, Bs, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_SW(rb1, Bs, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_SW(rb2, Bs, 0, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_SW(rb3, Bs, 0, 3); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; __syncthreads(); \
+  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 0, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 0, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 0, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 0, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB;
+
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
 
   const int nk = K / kTileK;
-  PFHIP_GL(ra0, Ag, lda, 0, 0); PFHIP_GL(ra1, Ag, lda, 1, 0); PFHIP_GL(ra2, Ag, lda, 2, 0); PFHIP_GL(ra3, Ag, lda, 3, 0);
-  PFHIP_GL(rb0, Wg, ldw, 0, 0); PFHIP_GL(rb1, Wg, ldw, 1, 0); PFHIP_GL(rb2, Wg, ldw, 2, 0); PFHIP_GL(rb3, Wg, ldw, 3, 0);
-  PFHIP_SW(ra0, As, 0, 0); PFHIP_SW(ra1, As, 0, 1); PFHIP_SW(ra2, As, 0, 2); PFHIP_SW(ra3, As, 0, 3);
-  PFHIP_SW(rb0, Bs, 0, 0); PFHIP_SW(rb1, Bs, 0, 1); PFHIP_SW(rb2, Bs, 0, 2); PFHIP_SW(rb3, Bs, 0, 3);
+  {
+    int knext = 0;
+    PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_GL(ra1, Ag, lda, 1, knext); PFHIP_GL(ra2, Ag, lda, 2, knext); PFHIP_GL(ra3, Ag, lda, 3, knext);
+    PFHIP_GL(rb0, Wg, ldw, 0, knext); PFHIP_GL(rb1, Wg, ldw, 1, knext); PFHIP_GL(rb2, Wg, ldw, 2, knext); PFHIP_GL(rb3, Wg, ldw, 3, knext);
+    PFHIP_SW(ra0, As, 0, 0); PFHIP_SW(ra1, As, 0, 1); PFHIP_SW(ra2, As, 0, 2); PFHIP_SW(ra3, As, 0, 3);
+    PFHIP_SW(rb0, Bs, 0, 0); PFHIP_SW(rb1, Bs, 0, 1); PFHIP_SW(rb2, Bs, 0, 2); PFHIP_SW(rb3, Bs, 0, 3);
+    knext = nk > 1 ? kTileK : 0;
+    PFHIP_GL(sa0, Ag, lda, 0, knext); PFHIP_GL(sa1, Ag, lda, 1, knext); PFHIP_GL(sa2, Ag, lda, 2, knext); PFHIP_GL(sa3, Ag, lda, 3, knext);
+    PFHIP_GL(sb0, Wg, ldw, 0, knext); PFHIP_GL(sb1, Wg, ldw, 1, knext); PFHIP_GL(sb2, Wg, ldw, 2, knext); PFHIP_GL(sb3, Wg, ldw, 3, knext);
+  }
   __syncthreads();
 
   const int a_off = (wr * 64 + r) * kLds + 4 * h;
@@ -86,83 +234,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   PFHIP_FR(fa0, As, a_off, 0, 0, 0); PFHIP_FR(fa1, As, a_off, 0, 0, 1);
   PFHIP_FR(fb0, Bs, b_off, 0, 0, 0); PFHIP_FR(fb1, Bs, b_off, 0, 0, 1);
 
-  // Software pipeline, one barrier per K-tile.  Per wave a K-tile is 64 MFMAs (4 k-blocks x 16) plus 8 global loads
-  // (next tile), 16 ds_read_b128 (fragments of the next k-block) and 8 ds_write_b128 (next tile into the other buffer).
-  // The memory instructions are issued ONE AT A TIME between single MFMAs, every statement pinned by a scheduling
-  // barrier: issued in bursts between groups of 16 MFMAs (the obvious layout) the same kernel is 15 % slower — each
-  // ds_read/global_load holds the wave's issue port long enough that a burst of 4-8 lets the matrix pipe run dry.
-  // The body below is generated (tools/probe/gen_gemm_loop.py, schedule "A"; tools/probe/gemm_sched.hip compares
-  // schedules): k-block 0 | global loads, reads of k-block 1;  k-block 1 | reads of k-block 2;  k-block 2 | reads of
-  // k-block 3, LDS writes, barrier;  k-block 3 | reads of k-block 0 of the next tile.
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    // unconditional (the last iteration re-fetches its own tile): keeps the loop body straight-line
-    const int knext = (kt + 1 < nk ? kt + 1 : kt) * kTileK;
-    PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_GL(ra1, Ag, lda, 1, knext); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_GL(ra2, Ag, lda, 2, knext); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_GL(ra3, Ag, lda, 3, knext); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_GL(rb0, Wg, ldw, 0, knext); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_GL(rb1, Wg, ldw, 1, knext); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_GL(rb2, Wg, ldw, 2, knext); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_GL(rb3, Wg, ldw, 3, knext); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_FR(ga0, As, a_off, cur, 1, 0); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_FR(ga1, As, a_off, cur, 1, 1); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, cur, 1, 0); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, cur, 1, 1); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, cur, 2, 0); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, cur, 2, 1); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, cur, 2, 0); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, cur, 2, 1); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_FR(ga0, As, a_off, cur, 3, 0); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_FR(ga1, As, a_off, cur, 3, 1); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, cur, 3, 0); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, cur, 3, 1); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_SW(ra0, As, cur ^ 1, 0); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_SW(ra1, As, cur ^ 1, 1); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_SW(ra2, As, cur ^ 1, 2); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_SW(ra3, As, cur ^ 1, 3); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_SW(rb0, Bs, cur ^ 1, 0); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_SW(rb1, Bs, cur ^ 1, 1); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_SW(rb2, Bs, cur ^ 1, 2); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_SW(rb3, Bs, cur ^ 1, 3); PFHIP_SB;
-    PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB;
-    PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB;
-    PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB;
-    PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; __syncthreads();
-    PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, cur ^ 1, 0, 0); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, cur ^ 1, 0, 1); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, cur ^ 1, 0, 0); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, cur ^ 1, 0, 1); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB;
-    PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB;
-    PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB;
-    PFHIP_MM(acc10, ga1.w, gb0.w); PFHIP_SB;
-    PFHIP_MM(acc11, ga1.w, gb1.w); PFHIP_SB;
+  // loads past the last K-tile re-fetch it (never used): keeps the bodies straight-line
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    { const int knext = (kt + 2 < nk ? kt + 2 : nk - 1) * kTileK; PFHIP_BODY_0 }
+    { const int knext = (kt + 3 < nk ? kt + 3 : nk - 1) * kTileK; PFHIP_BODY_1 }
   }
+  if (kt < nk) { const int knext = (nk - 1) * kTileK; PFHIP_BODY_0 }
+#undef PFHIP_BODY_0
+#undef PFHIP_BODY_1
 #undef PFHIP_SB
 #undef PFHIP_GL
 #undef PFHIP_SW

@@ -2,6 +2,7 @@
 //   python3 gen_gemm_loop.py > gemm_loop_gen.h && hipcc -O3 --offload-arch=gfx950 -ffp-contract=off gemm_sched.hip -o gemm_sched
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 #include "gemm_loop_gen.h"
@@ -28,23 +29,27 @@ constexpr int kLds = 36, kStage = 128 * kLds, kCs = 132;
     const int lrow = tid >> 3, lc4 = tid & 7;                                                                                 \
     const float* Ag = A + (size_t)(m0 + lrow) * lda + 4 * lc4;                                                                \
     const float* Wg = W + (size_t)(n0 + lrow) * ldw + 4 * lc4;                                                                \
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;                                                                            \
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;                                    \
     f32x16 acc00, acc01, acc10, acc11;                                                                                        \
     for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }                          \
-    { const int knext = 0; const int cur = 1;                                                                                 \
+    { int knext = 0;                                                                                                          \
       GL(ra0, Ag, lda, 0, knext); GL(ra1, Ag, lda, 1, knext); GL(ra2, Ag, lda, 2, knext); GL(ra3, Ag, lda, 3, knext);         \
       GL(rb0, Wg, ldw, 0, knext); GL(rb1, Wg, ldw, 1, knext); GL(rb2, Wg, ldw, 2, knext); GL(rb3, Wg, ldw, 3, knext);         \
-      SW(ra0, As, cur ^ 1, 0); SW(ra1, As, cur ^ 1, 1); SW(ra2, As, cur ^ 1, 2); SW(ra3, As, cur ^ 1, 3);                     \
-      SW(rb0, Bs, cur ^ 1, 0); SW(rb1, Bs, cur ^ 1, 1); SW(rb2, Bs, cur ^ 1, 2); SW(rb3, Bs, cur ^ 1, 3); }                   \
+      SW(ra0, As, 0, 0); SW(ra1, As, 0, 1); SW(ra2, As, 0, 2); SW(ra3, As, 0, 3);                                             \
+      SW(rb0, Bs, 0, 0); SW(rb1, Bs, 0, 1); SW(rb2, Bs, 0, 2); SW(rb3, Bs, 0, 3);                                             \
+      if (LOOP_PF_##NAME == 2) { knext = nk > 1 ? 32 : 0;                                                                     \
+        GL(sa0, Ag, lda, 0, knext); GL(sa1, Ag, lda, 1, knext); GL(sa2, Ag, lda, 2, knext); GL(sa3, Ag, lda, 3, knext);       \
+        GL(sb0, Wg, ldw, 0, knext); GL(sb1, Wg, ldw, 1, knext); GL(sb2, Wg, ldw, 2, knext); GL(sb3, Wg, ldw, 3, knext); } }   \
     __syncthreads();                                                                                                          \
     const int a_off = (wr * 64 + r) * kLds + 4 * h, b_off = (wc * 64 + r) * kLds + 4 * h;                                     \
     float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;                                                                            \
     FR(fa0, As, a_off, 0, 0, 0); FR(fa1, As, a_off, 0, 0, 1); FR(fb0, Bs, b_off, 0, 0, 0); FR(fb1, Bs, b_off, 0, 0, 1);       \
-    for (int kt = 0; kt < nk; ++kt) {                                                                                         \
-      const int cur = kt & 1;                                                                                                 \
-      const int knext = (kt + 1 < nk ? kt + 1 : kt) * 32;                                                                     \
-      LOOP_BODY_##NAME                                                                                                        \
+    int kt = 0;                                                                                                               \
+    for (; kt + 1 < nk; kt += 2) {                                                                                            \
+      { const int knext = (kt + LOOP_PF_##NAME < nk ? kt + LOOP_PF_##NAME : nk - 1) * 32; LOOP_BODY_##NAME##_0 }              \
+      { const int knext = (kt + 1 + LOOP_PF_##NAME < nk ? kt + 1 + LOOP_PF_##NAME : nk - 1) * 32; LOOP_BODY_##NAME##_1 }      \
     }                                                                                                                         \
+    if (kt < nk) { const int knext = (nk - 1) * 32; LOOP_BODY_##NAME##_0 }                                                    \
     __syncthreads();                                                                                                          \
     float* const Cs = lds;                                                                                                    \
     { float* cw = Cs + (wr * 64 + 4 * h) * kCs + wc * 64 + r;                                                                 \
@@ -56,23 +61,66 @@ constexpr int kLds = 36, kStage = 128 * kLds, kCs = 132;
       *(float4*)(C + (size_t)(m0 + row) * ldc + n0 + 4 * c4) = *(const float4*)(Cs + row * kCs + 4 * c4); }                   \
   }
 
-KERNEL(A) KERNEL(B) KERNEL(C) KERNEL(D) KERNEL(E)
+KERNEL(A) KERNEL(F) KERNEL(G) KERNEL(H)
+// knock-out copies of schedule A (timing only; results are wrong)
+#define LOOP_PF_A_nobar 1
+#define LOOP_PF_A_nogl 1
+#define LOOP_PF_A_nosw 1
+#define LOOP_PF_A_noglsw 1
+#define LOOP_PF_A_nomem 1
+#define LOOP_BODY_A_nobar_0 LOOP_BODY_A_0
+#define LOOP_BODY_A_nobar_1 LOOP_BODY_A_1
+#define LOOP_BODY_A_nogl_0 LOOP_BODY_A_0
+#define LOOP_BODY_A_nogl_1 LOOP_BODY_A_1
+#define LOOP_BODY_A_nosw_0 LOOP_BODY_A_0
+#define LOOP_BODY_A_nosw_1 LOOP_BODY_A_1
+#define LOOP_BODY_A_noglsw_0 LOOP_BODY_A_0
+#define LOOP_BODY_A_noglsw_1 LOOP_BODY_A_1
+#define LOOP_BODY_A_nomem_0 LOOP_BODY_A_0
+#define LOOP_BODY_A_nomem_1 LOOP_BODY_A_1
+#pragma push_macro("__syncthreads")
+#define __syncthreads() asm volatile("" ::: "memory")
+KERNEL(A_nobar)
+#pragma pop_macro("__syncthreads")
+#pragma push_macro("GL")
+#undef GL
+#define GL(reg, base, ld, j, k0) asm volatile("" : "+v"(reg.x))
+KERNEL(A_nogl)
+#pragma push_macro("SW")
+#undef SW
+#define SW(reg, base, buf, j) asm volatile("" :: "v"(reg.x))
+KERNEL(A_noglsw)
+#pragma push_macro("__syncthreads")
+#define __syncthreads() asm volatile("" ::: "memory")
+KERNEL(A_nomem)
+#pragma pop_macro("__syncthreads")
+#pragma pop_macro("SW")
+#pragma pop_macro("GL")
+#pragma push_macro("SW")
+#undef SW
+#define SW(reg, base, buf, j) asm volatile("" :: "v"(reg.x))
+KERNEL(A_nosw)
+#pragma pop_macro("SW")
+
 typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int);
-static kern_t kernels[] = {gemm_A, gemm_B, gemm_C, gemm_D, gemm_E};
-static const char* names[] = {"A", "B", "C", "D", "E"};
+static kern_t kernels[] = {gemm_A, gemm_F, gemm_G, gemm_H, gemm_A_nogl, gemm_A_nomem};
+static const char* names[] = {"A", "F", "G", "H", "nogl", "nomem"};
 
 float run(kern_t k, const float* A, const float* W, float* C, int M, int N, int K, int iters) {
   const int tiles_n = N / 128, blocks = (M / 128) * tiles_n;
+  const int grid = blocks;
+  const size_t dyn = getenv("SOLO") ? 60 * 1024 : 0;     // extra dynamic LDS: only one block fits a CU
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, A, W, C, K, K, N, K / 32, tiles_n, blocks);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), dyn, 0, A, W, C, K, K, N, K / 32, tiles_n, blocks);
   hipEventRecord(e0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, A, W, C, K, K, N, K / 32, tiles_n, blocks);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), dyn, 0, A, W, C, K, K, N, K / 32, tiles_n, blocks);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms / iters;
 }
 
 int main() {
+  if (getenv("SOLO")) for (auto k : kernels) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
   const int shapes[4][3] = {{16000, 2048, 512}, {16000, 512, 2048}, {16000, 1536, 512}, {16000, 512, 512}};
   const int nv = sizeof(kernels) / sizeof(kernels[0]);
   for (auto& s : shapes) {
@@ -93,7 +141,7 @@ int main() {
       double md = 0; if (v) for (size_t i = 0; i < c0.size(); ++i) md = fmax(md, fabs((double)c0[i] - c1[i]));
       float best = 1e9f;
       for (int rep = 0; rep < 3; ++rep) best = fminf(best, run(kernels[v], A, W, C, M, N, K, 20));
-      printf("  %s %6.1f us %5.1f TF%s", names[v], best * 1e3, fl / best / 1e9, md == 0 ? "" : " MISMATCH");
+      printf("  %s %6.1f us %5.1f TF", names[v], best * 1e3, fl / best / 1e9);
     }
     printf("\n");
     hipFree(A); hipFree(W); hipFree(C);

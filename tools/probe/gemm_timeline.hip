@@ -58,10 +58,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tl(const float* __restrict__ A, c
 #define SW(reg, base, buf, j) *(float4*)(base + (buf) * kStage + lrow * kLds + 4 * lc4 + 32 * (j) * kLds) = reg
 #define FR(reg, base, off, buf, kb, j) reg = *(const float4*)(base + (buf) * kStage + off + (kb) * 8 + 32 * (j) * kLds)
 #define MM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const int knext = (kt + 1 < nk ? kt + 1 : kt) * 32;
-    LOOP_BODY_A
+  for (int kt = 0; kt < nk; kt += 2) {
+    { const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * 32; LOOP_BODY_A_0 }
+    { const int knext = (kt + 2 < nk ? kt + 2 : nk - 1) * 32; LOOP_BODY_A_1 }
   }
   __syncthreads();
   const unsigned long long t2 = wall_clock64();
@@ -111,6 +110,19 @@ static void analyse(const std::vector<Rec>& v, const char* name, double flops, f
   const double tot = (double)(tmax - tmin) * cu.size();
   printf("   %zu CUs seen, %zu..%zu blocks per CU; CU time with 0/1/2 resident blocks: %.1f / %.1f / %.1f %%;  with 0/1/2 blocks inside the K loop: %.1f / %.1f / %.1f %%\n",
          cu.size(), mn, mx, 100 * res[0] / tot, 100 * res[1] / tot, 100 * res[2] / tot, 100 * inl[0] / tot, 100 * inl[1] / tot, 100 * inl[2] / tot);
+  // loop duration of a block vs. the share of that time during which another block of the same CU was in its K loop
+  { double sum[5] = {0, 0, 0, 0, 0}; int cnt[5] = {0, 0, 0, 0, 0};
+    for (auto& kv : cu)
+      for (auto* q : kv.second) {
+        double ov = 0;
+        for (auto* o : kv.second) if (o != q) { const unsigned long long lo = std::max(q->t1, o->t1), hi = std::min(q->t2, o->t2); if (hi > lo) ov += (double)(hi - lo); }
+        const double f = ov / (double)(q->t2 - q->t1);
+        const int b = std::min(4, (int)(f * 5));
+        sum[b] += (double)(q->t2 - q->t1) * tick; cnt[b]++;
+      }
+    printf("   K-loop time by co-resident overlap share [0-20%%,..,80-100%%]:");
+    for (int b = 0; b < 5; ++b) printf("  %.1f us (n=%d)", cnt[b] ? sum[b] / cnt[b] : 0.0, cnt[b]);
+    printf("\n"); }
   // start-time histogram in 10 us buckets: does the grid move in lock-step rounds?
   const int nb = (int)((tmax - tmin) * tick / 10) + 1;
   std::vector<int> hs(nb, 0), he(nb, 0);
@@ -121,6 +133,8 @@ static void analyse(const std::vector<Rec>& v, const char* name, double flops, f
 }
 
 int main(int argc, char** argv) {
+  const size_t dyn = getenv("SOLO") ? 60 * 1024 : 0;
+  if (dyn) hipFuncSetAttribute((const void*)gemm_tl, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
   struct Shape { int M, N, K; bool res; const char* name; };
   const Shape shapes[] = {{16000, 2048, 512, false, "ffn1 16000x2048x512"}, {16000, 512, 2048, true, "ffn2 16000x512x2048 +res"},
                           {16000, 1536, 512, false, "qkv 16000x1536x512"}, {16000, 512, 512, true, "out 16000x512x512 +res"}};
@@ -136,12 +150,12 @@ int main(int argc, char** argv) {
     const int tiles_n = N / 128, blocks = (M / 128) * tiles_n;
     hipMalloc(&rec, blocks * sizeof(Rec));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_tl, dim3(blocks), dim3(256), 0, 0, A, W, C, s.res ? R : nullptr, K, K, N, K / 32, tiles_n, blocks, (Rec*)nullptr);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_tl, dim3(blocks), dim3(256), dyn, 0, A, W, C, s.res ? R : nullptr, K, K, N, K / 32, tiles_n, blocks, (Rec*)nullptr);
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(gemm_tl, dim3(blocks), dim3(256), 0, 0, A, W, C, s.res ? R : nullptr, K, K, N, K / 32, tiles_n, blocks, (Rec*)nullptr);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(gemm_tl, dim3(blocks), dim3(256), dyn, 0, A, W, C, s.res ? R : nullptr, K, K, N, K / 32, tiles_n, blocks, (Rec*)nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
-    hipLaunchKernelGGL(gemm_tl, dim3(blocks), dim3(256), 0, 0, A, W, C, s.res ? R : nullptr, K, K, N, K / 32, tiles_n, blocks, rec);
+    hipLaunchKernelGGL(gemm_tl, dim3(blocks), dim3(256), dyn, 0, A, W, C, s.res ? R : nullptr, K, K, N, K / 32, tiles_n, blocks, rec);
     hipDeviceSynchronize();
     std::vector<Rec> v(blocks);
     hipMemcpy(v.data(), rec, blocks * sizeof(Rec), hipMemcpyDeviceToHost);

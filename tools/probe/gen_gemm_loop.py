@@ -12,8 +12,8 @@ import sys
 SCHEDULES = {}
 
 
-def sched(name, table, barrier=(2, 15)):
-    SCHEDULES[name] = (table, barrier)
+def sched(name, table, barrier=(2, 15), pf=1):
+    SCHEDULES[name] = (table, barrier, pf)
 
 
 def spread(ops, slots):
@@ -53,27 +53,54 @@ sched("D", {0: merge(spread(G, range(0, 8)), spread(R(1), range(8, 12))), 1: spr
 sched("E", {0: merge(spread(G, range(0, 8)), spread(R(1), range(9, 13))), 1: spread(R(2), range(8, 12)),
             2: merge(spread(W, range(0, 8)), spread(R(3), range(8, 12))), 3: spread(R(4), range(8, 12))})
 
-REGS = ["ra0", "ra1", "ra2", "ra3", "rb0", "rb1", "rb2", "rb3"]
+# F: LDS writes as late as the dependences allow (barrier in the middle of k-block 3): more time for the global loads
+sched("F", {0: merge(spread(G, range(0, 8)), spread(R(1), range(8, 12))), 1: spread(R(2), range(0, 4)),
+            2: merge(spread(R(3), range(0, 4)), spread(W[:4], range(12, 16))),
+            3: merge(spread(W[4:], range(0, 4)), spread(R(4), range(7, 11)))}, barrier=(3, 6))
+# G: schedule A with prefetch distance 2 (two staging register sets, loop unrolled by 2)
+sched("G", {0: merge(spread(G, range(0, 8)), spread(R(1), range(8, 12))), 1: spread(R(2), range(0, 4)),
+            2: merge(spread(R(3), range(0, 4)), spread(W, range(4, 12))), 3: spread(R(4), range(0, 4))}, pf=2)
+# H: F with prefetch distance 2
+sched("H", {0: merge(spread(G, range(0, 8)), spread(R(1), range(8, 12))), 1: spread(R(2), range(0, 4)),
+            2: merge(spread(R(3), range(0, 4)), spread(W[:4], range(12, 16))),
+            3: merge(spread(W[4:], range(0, 4)), spread(R(4), range(7, 11)))}, barrier=(3, 6), pf=2)
+
+# S: schedule H + the write-out of the PREVIOUS output tile (persistent kernel): per K-tile one 8-row pass of the C tile:
+#    E0 = residual loads, E1 = C-staging read from LDS, E2 = bias/residual/ReLU + global store
+sched("S", {0: merge(spread(G, range(0, 8)), spread(R(1), range(8, 12)), {13: ["E0"]}), 1: merge(spread(R(2), range(0, 4)), {8: ["E1"]}),
+            2: merge(spread(R(3), range(0, 4)), {8: ["E2"]}, spread(W[:4], range(12, 16))),
+            3: merge(spread(W[4:], range(0, 4)), spread(R(4), range(7, 11)))}, barrier=(3, 6), pf=2)
+
+REGS = [["ra0", "ra1", "ra2", "ra3", "rb0", "rb1", "rb2", "rb3"], ["sa0", "sa1", "sa2", "sa3", "sb0", "sb1", "sb2", "sb3"]]
 
 
-def emit_op(op):
+def emit_op(op, cur, lset, sset):
+    if op[0] == "E":
+        return f"EP{op[1]}();"
     if op[0] == "G":
         j = int(op[1])
         base, ld = ("Ag", "lda") if j < 4 else ("Wg", "ldw")
-        return f"GL({REGS[j]}, {base}, {ld}, {j % 4}, knext);"
+        return f"GL({REGS[lset][j]}, {base}, {ld}, {j % 4}, knext);"
     if op[0] == "W":
         j = int(op[1])
-        return f"SW({REGS[j]}, {'As' if j < 4 else 'Bs'}, cur ^ 1, {j % 4});"
+        return f"SW({REGS[sset][j]}, {'As' if j < 4 else 'Bs'}, {cur ^ 1}, {j % 4});"
     k, j = int(op[1]), int(op[3])
     s = "f" if k % 2 == 0 else "g"
     reg = f"{s}{'a' if j < 2 else 'b'}{j % 2}"
-    buf, kb = ("cur ^ 1", 0) if k == 4 else ("cur", k)
+    buf, kb = (str(cur ^ 1), 0) if k == 4 else (str(cur), k)
     base, off = ("As", "a_off") if j < 2 else ("Bs", "b_off")
     return f"FR({reg}, {base}, {off}, {buf}, {kb}, {j % 2});"
 
 
 def emit(name):
-    table, barrier = SCHEDULES[name]
+    """Two bodies per schedule: _0 for even K-tiles (LDS buffer 0 is current), _1 for odd ones."""
+    return emit_half(name, 0) + "\n" + emit_half(name, 1)
+
+
+def emit_half(name, cur):
+    table, barrier, pf = SCHEDULES[name]
+    lset = cur if pf == 2 else 0          # pf 2: tile kt+2 is loaded into set (kt & 1), tile kt+1 stored from the other
+    sset = 1 - cur if pf == 2 else 0
     lines = []
     for g in range(4):
         s = "f" if g % 2 == 0 else "g"
@@ -84,11 +111,11 @@ def emit(name):
             b = f"{s}b{(i % 4) % 2}.{c}"
             line = f"MM({acc}, {a}, {b}); SB;"
             for op in table.get(g, {}).get(i, []):
-                line += " " + emit_op(op) + " SB;"
+                line += " " + emit_op(op, cur, lset, sset) + " SB;"
             if (g, i) == barrier:
                 line += " __syncthreads();"
             lines.append(line)
-    return f"#define LOOP_BODY_{name} \\\n" + " \\\n".join("  " + l for l in lines) + "\n"
+    return f"#define LOOP_BODY_{name}_{cur} \\\n" + " \\\n".join("  " + l for l in lines) + "\n"
 
 
 if __name__ == "__main__":
@@ -96,4 +123,5 @@ if __name__ == "__main__":
     print("// generated by gen_gemm_loop.py — do not edit")
     for n in names:
         print(emit(n))
-    print("#define SCHED_NAMES " + ", ".join(f'"{n}"' for n in names))
+    for n in names:
+        print(f"#define LOOP_PF_{n} {SCHEDULES[n][2]}")

@@ -76,11 +76,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   // one iteration earlier, into the other LDS buffer).  The memory instructions are issued ONE AT A TIME between
   // single MFMAs, every statement pinned by a scheduling barrier: issued in bursts between groups of 16 MFMAs (the
   // obvious layout) the same kernel is 15 % slower — each ds_read/global_load holds the wave's issue port long enough
-  // that a burst of 4-8 lets the matrix pipe run dry.  Prefetch distance 2 is worth +5 % at K = 2048 and nothing at
-  // K = 512.  The two bodies are generated (tools/probe/gen_gemm_loop.py, schedule "G"; tools/probe/gemm_sched.hip
-  // compares schedules): _0 computes from LDS buffer 0 (even K-tiles), loads into r*, stores s*; _1 the mirror image.
+  // that a burst of 4-8 lets the matrix pipe run dry.  Prefetch distance 2 plus LDS writes as late as the dependences
+  // allow (barrier in the middle of k-block 3) are worth another +3..12 % (interleaved A/B runs, warm clocks).
+  // The two bodies are generated (tools/probe/gen_gemm_loop.py, schedule "H"; tools/probe/gemm_sched.hip compares
+  // schedules): _0 computes from LDS buffer 0 (even K-tiles), loads into r*, stores s*; _1 the mirror image.
   //   k-block 0 | global loads, reads of k-block 1;  k-block 1 | reads of k-block 2;
-  //   k-block 2 | reads of k-block 3, LDS writes, barrier;  k-block 3 | reads of k-block 0 of the next tile.
+  //   k-block 2 | reads of k-block 3, first half of the LDS writes;
+  //   k-block 3 | second half of the LDS writes, barrier, reads of k-block 0 of the next tile.
 #define PFHIP_BODY_0 \
   PFHIP_MM(acc00, fa0.x, fb0.x); PFHIP_SB; PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_SB; \
   PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_GL(ra1, Ag, lda, 1, knext); PFHIP_SB; \
@@ -118,29 +120,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_FR(ga1, As, a_off, 0, 3, 1); PFHIP_SB; \
   PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, 0, 3, 0); PFHIP_SB; \
   PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, 0, 3, 1); PFHIP_SB; \
-  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_SW(sa0, As, 1, 0); PFHIP_SB; \
-  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_SW(sa1, As, 1, 1); PFHIP_SB; \
-  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_SW(sa2, As, 1, 2); PFHIP_SB; \
-  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_SW(sa3, As, 1, 3); PFHIP_SB; \
-  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_SW(sb0, Bs, 1, 0); PFHIP_SB; \
-  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_SW(sb1, Bs, 1, 1); PFHIP_SB; \
-  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_SW(sb2, Bs, 1, 2); PFHIP_SB; \
-  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_SW(sb3, Bs, 1, 3); PFHIP_SB; \
-  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; \
-  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; \
-  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; \
-  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; __syncthreads(); \
-  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 1, 0, 0); PFHIP_SB; \
-  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 1, 0, 1); PFHIP_SB; \
-  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 1, 0, 0); PFHIP_SB; \
-  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 1, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; PFHIP_SW(sa0, As, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; PFHIP_SW(sa1, As, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; PFHIP_SW(sa2, As, 1, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; PFHIP_SW(sa3, As, 1, 3); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_SW(sb0, Bs, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_SW(sb1, Bs, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_SW(sb2, Bs, 1, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_SW(sb3, Bs, 1, 3); PFHIP_SB; \
   PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB; \
   PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB; \
-  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; \
-  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; \
-  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; \
-  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; \
-  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; __syncthreads(); \
+  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 1, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 1, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 1, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 1, 0, 1); PFHIP_SB; \
   PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB; \
   PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB; \
   PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB; \
@@ -183,29 +185,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   PFHIP_MM(acc01, fa0.x, fb1.x); PFHIP_SB; PFHIP_FR(ga1, As, a_off, 1, 3, 1); PFHIP_SB; \
   PFHIP_MM(acc10, fa1.x, fb0.x); PFHIP_SB; PFHIP_FR(gb0, Bs, b_off, 1, 3, 0); PFHIP_SB; \
   PFHIP_MM(acc11, fa1.x, fb1.x); PFHIP_SB; PFHIP_FR(gb1, Bs, b_off, 1, 3, 1); PFHIP_SB; \
-  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; PFHIP_SW(ra0, As, 0, 0); PFHIP_SB; \
-  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; PFHIP_SW(ra1, As, 0, 1); PFHIP_SB; \
-  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; PFHIP_SW(ra2, As, 0, 2); PFHIP_SB; \
-  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; PFHIP_SW(ra3, As, 0, 3); PFHIP_SB; \
-  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; PFHIP_SW(rb0, Bs, 0, 0); PFHIP_SB; \
-  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; PFHIP_SW(rb1, Bs, 0, 1); PFHIP_SB; \
-  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; PFHIP_SW(rb2, Bs, 0, 2); PFHIP_SB; \
-  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; PFHIP_SW(rb3, Bs, 0, 3); PFHIP_SB; \
-  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; \
-  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; \
-  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; \
-  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; __syncthreads(); \
-  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 0, 0, 0); PFHIP_SB; \
-  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 0, 0, 1); PFHIP_SB; \
-  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 0, 0, 0); PFHIP_SB; \
-  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 0, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.y, fb0.y); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.y, fb1.y); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.y, fb0.y); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.y, fb1.y); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.z, fb0.z); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.z, fb1.z); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.z, fb0.z); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.z, fb1.z); PFHIP_SB; \
+  PFHIP_MM(acc00, fa0.w, fb0.w); PFHIP_SB; PFHIP_SW(ra0, As, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, fa0.w, fb1.w); PFHIP_SB; PFHIP_SW(ra1, As, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, fa1.w, fb0.w); PFHIP_SB; PFHIP_SW(ra2, As, 0, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, fa1.w, fb1.w); PFHIP_SB; PFHIP_SW(ra3, As, 0, 3); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.x, gb0.x); PFHIP_SB; PFHIP_SW(rb0, Bs, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.x, gb1.x); PFHIP_SB; PFHIP_SW(rb1, Bs, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.x, gb0.x); PFHIP_SB; PFHIP_SW(rb2, Bs, 0, 2); PFHIP_SB; \
+  PFHIP_MM(acc11, ga1.x, gb1.x); PFHIP_SB; PFHIP_SW(rb3, Bs, 0, 3); PFHIP_SB; \
   PFHIP_MM(acc00, ga0.y, gb0.y); PFHIP_SB; \
   PFHIP_MM(acc01, ga0.y, gb1.y); PFHIP_SB; \
-  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; \
-  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; \
-  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; \
-  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; \
-  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.y, gb0.y); PFHIP_SB; __syncthreads(); \
+  PFHIP_MM(acc11, ga1.y, gb1.y); PFHIP_SB; PFHIP_FR(fa0, As, a_off, 0, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc00, ga0.z, gb0.z); PFHIP_SB; PFHIP_FR(fa1, As, a_off, 0, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc01, ga0.z, gb1.z); PFHIP_SB; PFHIP_FR(fb0, Bs, b_off, 0, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc10, ga1.z, gb0.z); PFHIP_SB; PFHIP_FR(fb1, Bs, b_off, 0, 0, 1); PFHIP_SB; \
   PFHIP_MM(acc11, ga1.z, gb1.z); PFHIP_SB; \
   PFHIP_MM(acc00, ga0.w, gb0.w); PFHIP_SB; \
   PFHIP_MM(acc01, ga0.w, gb1.w); PFHIP_SB; \

@@ -14,6 +14,7 @@ constexpr int kLds = 36, kStage = 128 * kLds, kCs = 132;
 #define FR(reg, base, off, buf, kb, j) reg = *(const float4*)(base + (buf) * kStage + off + (kb) * 8 + 32 * (j) * kLds)
 #define MM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
+__constant__ int g_gw;
 #define KERNEL(NAME)                                                                                                          \
   __global__ __launch_bounds__(256, 2) void gemm_##NAME(const float* __restrict__ A, const float* __restrict__ W, float* C,   \
                                                         int lda, int ldw, int ldc, int nk, int tiles_n, int n_tiles) {        \
@@ -22,7 +23,10 @@ constexpr int kLds = 36, kStage = 128 * kLds, kCs = 132;
     int bid = blockIdx.x;                                                                                                     \
     { const int q = n_tiles >> 3, rr = n_tiles & 7, xcd = bid & 7;                                                            \
       bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3); }                                        \
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;                                                                    \
+    int tm = bid / tiles_n, tn = bid - tm * tiles_n;                                                                          \
+    if (g_gw > 0) { const int tiles_m = n_tiles / tiles_n, full = tiles_n / g_gw, span = tiles_m * g_gw;                      \
+      if (bid < full * span) { const int g = bid / span, j = bid - g * span; tm = j / g_gw; tn = g * g_gw + (j - tm * g_gw); } \
+      else { const int j = bid - full * span, w = tiles_n - full * g_gw; tm = j / w; tn = full * g_gw + (j - tm * w); } }     \
     const int m0 = tm * 128, n0 = tn * 128;                                                                                   \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                                            \
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;                                                    \
@@ -104,6 +108,7 @@ KERNEL(A_nosw)
 
 typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int);
 static kern_t kernels[] = {gemm_A, gemm_F, gemm_G, gemm_H, gemm_A_nogl, gemm_A_nomem};
+static int gws[] = {0, 0, 0, 0, 0, 0};
 static const char* names[] = {"A", "F", "G", "H", "nogl", "nomem"};
 
 float run(kern_t k, const float* A, const float* W, float* C, int M, int N, int K, int iters) {
@@ -121,7 +126,7 @@ float run(kern_t k, const float* A, const float* W, float* C, int M, int N, int 
 
 int main() {
   if (getenv("SOLO")) for (auto k : kernels) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
-  const int shapes[4][3] = {{16000, 2048, 512}, {16000, 512, 2048}, {16000, 1536, 512}, {16000, 512, 512}};
+  const int shapes[6][3] = {{16000, 2048, 512}, {16000, 512, 2048}, {16000, 1536, 512}, {16000, 512, 512}, {16000, 1024, 512}, {7040, 8448, 512}};
   const int nv = sizeof(kernels) / sizeof(kernels[0]);
   for (auto& s : shapes) {
     const int M = s[0], N = s[1], K = s[2];
@@ -134,15 +139,14 @@ int main() {
     const double fl = 2.0 * M * N * K;
     std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
     printf("%5dx%4dx%4d:", M, N, K);
-    for (int v = 0; v < nv; ++v) {
-      hipMemset(C, 0, c0.size() * 4);
-      run(kernels[v], A, W, C, M, N, K, 1);
-      hipMemcpy(v == 0 ? c0.data() : c1.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
-      double md = 0; if (v) for (size_t i = 0; i < c0.size(); ++i) md = fmax(md, fabs((double)c0[i] - c1[i]));
-      float best = 1e9f;
-      for (int rep = 0; rep < 3; ++rep) best = fminf(best, run(kernels[v], A, W, C, M, N, K, 20));
-      printf("  %s %6.1f us %5.1f TF", names[v], best * 1e3, fl / best / 1e9);
-    }
+    std::vector<float> best(nv, 1e9f);
+    for (int rep = 0; rep < 4; ++rep)            // variants interleaved: clock ramp / thermal drift hits all of them alike
+      for (int v = 0; v < nv; ++v) {
+        hipMemcpyToSymbol(HIP_SYMBOL(g_gw), &gws[v], sizeof(int));
+        const float t = run(kernels[v], A, W, C, M, N, K, 30);
+        if (rep > 0) best[v] = fminf(best[v], t);
+      }
+    for (int v = 0; v < nv; ++v) printf("  %s %6.1f us %5.1f TF", names[v], best[v] * 1e3, fl / best[v] / 1e9);
     printf("\n");
     hipFree(A); hipFree(W); hipFree(C);
   }

@@ -4,9 +4,22 @@ import re
 import sys
 from collections import defaultdict
 
+def records(path):
+    """csv (kernel_trace.csv) or the rocpd sqlite database rocprofv3 writes by default (results.db)."""
+    if path.endswith(".db"):
+        import sqlite3
+        con = sqlite3.connect(path)
+        for r in con.execute("select name, grid_x, grid_y, grid_z, workgroup_x, workgroup_y, workgroup_z, vgpr_count, lds_size, start, end from kernels"):
+            yield {"Kernel_Name": r[0], "Grid_Size_X": r[1], "Grid_Size_Y": r[2] // max(1, r[5]), "Grid_Size_Z": r[3] // max(1, r[6]),
+                   "Workgroup_Size_X": r[4], "VGPR_Count": str(r[7]), "LDS_Block_Size": str(r[8]), "Start_Timestamp": r[9], "End_Timestamp": r[10]}
+    else:
+        with open(path) as f:
+            yield from csv.DictReader(f)
+
+
 rows = defaultdict(list)
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
+if True:
+    for r in records(sys.argv[1]):
         name = r["Kernel_Name"].replace("pfhip::(anonymous namespace)::", "").replace("void ", "")
         name = re.sub(r"\(.*", "", name)
         key = (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]),

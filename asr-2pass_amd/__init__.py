@@ -50,6 +50,10 @@ class _Out(ctypes.Structure):
         ("n_frames", ctypes.POINTER(ctypes.c_int32)),
         ("logp", ctypes.POINTER(ctypes.c_float)),
         ("max_tokens", ctypes.c_int32),
+        ("us_alphas", ctypes.POINTER(ctypes.c_float)),
+        ("us_peaks", ctypes.POINTER(ctypes.c_float)),
+        ("us_len", ctypes.POINTER(ctypes.c_int32)),
+        ("max_us", ctypes.c_int32),
     ]
 
 
@@ -234,9 +238,9 @@ class ParaformerHip:
         _check(self._lib, self._lib.pfhip_hotword_embed(self._h, mat.ctypes.data, ln.ctypes.data, len(rows), out.ctypes.data))
         return out
 
-    def forward_ids(self, din: Sequence[np.ndarray], want_logp=False, max_tokens=None, hw_emb=None):
+    def forward_ids(self, din: Sequence[np.ndarray], want_logp=False, max_tokens=None, hw_emb=None, want_timestamps=False):
         """Batched forward.  Returns dict(token_num, n_fires, n_frames, ids=list of int arrays,
-        logp=list of [n_fires, V] arrays or None)."""
+        logp=list of [n_fires, V] arrays or None[, us_alphas, us_peaks = lists of [3*T_b] arrays])."""
         B = len(din)
         if B == 0:
             raise PfhipError("empty batch")
@@ -258,12 +262,25 @@ class ParaformerHip:
         out.n_frames = fr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
         out.logp = logp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_logp else None
         out.max_tokens = max_tokens
+        if want_timestamps:
+            max_us = 3 * max(1, max(int(b.shape[0]) for b in bufs) // 960 + 2)
+            usa = np.zeros((B, max_us), np.float32)
+            usp = np.zeros((B, max_us), np.float32)
+            usl = np.zeros(B, np.int32)
+            out.us_alphas = usa.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            out.us_peaks = usp.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            out.us_len = usl.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+            out.max_us = max_us
         hw = np.ascontiguousarray(hw_emb, dtype=np.float32) if hw_emb is not None else None
         _check(self._lib, self._lib.pfhip_offline_forward(self._h, ptrs, lens, B, hw.ctypes.data if hw is not None else None,
                                                           int(hw.shape[0]) if hw is not None else 0, ctypes.byref(out)))
-        return dict(token_num=tn, n_fires=nf, n_frames=fr,
-                    ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)],
-                    logp=[logp[b, :nf[b]].copy() for b in range(B)] if want_logp else None)
+        res = dict(token_num=tn, n_fires=nf, n_frames=fr,
+                   ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)],
+                   logp=[logp[b, :nf[b]].copy() for b in range(B)] if want_logp else None)
+        if want_timestamps:
+            res["us_alphas"] = [usa[b, :usl[b]].copy() for b in range(B)]
+            res["us_peaks"] = [usp[b, :usl[b]].copy() for b in range(B)]
+        return res
 
     def Forward(self, din, len_=None, input_finished=True, hw_emb=None, decoder_handle=None, batch_in=1):
         """Same contract as Model::Forward: returns batch_in strings; an utterance that yields no

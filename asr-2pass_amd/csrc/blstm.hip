@@ -1,0 +1,261 @@
+// CifPredictorV3 timestamp head (the producer of the us_alphas / us_cif_peak tensors that
+// Paraformer::Forward hands to TimestampOnnx, onnxruntime/src/paraformer.cpp:545-562): the bidirectional LSTM over the
+// x3-upsampled encoder frames, the alpha head and the cif_wo_hidden scan.  The two GEMM-shaped parts (ConvTranspose1d as
+// a [T,512]x[512,1536] product, the LSTM input projection for all frames and both directions) run on gemm.hip.
+//
+// The recurrence is the only serial part of the whole model: 3T steps (1500 for 30 s) of h[B,512] x W_hh^T[512,2048] per
+// direction, with all of h exchanged between the steps.  One PERSISTENT kernel runs all steps.  Where the blocks run is
+// the design decision: the 8 XCDs' L2 caches are not coherent with each other, so a step barrier across XCDs needs an
+// agent-scope release + acquire (L2 write-back + invalidate) — measured 37 us per step with cooperative_groups'
+// grid.sync() and the same with hand-rolled fences, 56 ms for a 30-s batch.  Instead EACH DIRECTION LIVES ON ONE XCD
+// (workgroup i is dispatched to XCD i % 8: direction d = blocks with blockIdx % 8 == d): its 32 blocks exchange h
+// through that XCD's own L2, which is coherent for them — plain stores (L1 is write-through) + `s_waitcnt vmcnt(0)`,
+// a counter in the same L2, and `sc1` loads that bypass the reader's L1.  No cache-wide operation in the loop.
+// A block owns 16 hidden units x 4 gates = 64 rows of W_hh, held in VGPRs as MFMA B fragments for the whole sequence;
+// per step it reads the previous h[B,512] (64 KB, L2), runs 2 x 4 x 16 v_mfma_f32_16x16x4_f32 per wave (the 8 waves
+// split K), reduces through LDS, updates its 16 x B cells (c stays in registers) and publishes 16 x B new h values.
+// All utterances of a launch (<= 32) advance together; each walks its own frames (packed layout, no padding frames: a
+// padded batch would feed pad frames into the backward direction).  Placement is verified on the device (XCC_ID).
+#include "kernels.h"
+
+#include <math.h>
+
+namespace pfhip {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kH = 512;              // LSTM hidden size (= d_model)
+constexpr int kUnits = 16;           // hidden units per block
+constexpr int kBlocksPerDir = kH / kUnits;     // 32 = the CUs of one XCD
+constexpr int kMaxB = 32;            // utterances per launch (2 MFMA row tiles)
+constexpr int kXcds = 8;
+constexpr int kBlstmThreads = 512;   // 8 waves split K = 512 eight ways: 16 consecutive k per lane
+constexpr int kWaves = kBlstmThreads / 64;
+constexpr int kKL = kH / kWaves / 4;  // k per lane (4 lane groups per wave)
+// barrier words after the exchange buffer: [0],[1] step counters, [2] error flag, [4],[5] XCC id + 1 of each direction
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// 64 contiguous bytes per lane, loaded past this CU's L1 (`sc1`: the data was written by other CUs of the same XCD since
+// the last step).  The loads AND their wait are one asm statement: the compiler does not count asm loads, so outside
+// of it the destination registers could be copied before the data has landed.
+__device__ __forceinline__ void load16_l2(const float* p, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n"
+      "global_load_dwordx4 %1, %4, off offset:16 sc1\n"
+      "global_load_dwordx4 %2, %4, off offset:32 sc1\n"
+      "global_load_dwordx4 %3, %4, off offset:48 sc1\n"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(p)
+      : "memory");
+}
+static_assert(kH / (kBlstmThreads / 64) / 4 == 16, "load16_l2 moves exactly one lane's K slice");
+
+// gx   [rows, 2*4H]  input projections + biases, forward gates then backward gates (i,f,g,o blocks of H each)
+// whh  [2][4H][H]
+// y    [rows, 2H]    forward h | backward h
+// hx   [2 dir][2 parity][kMaxB][H]  exchange buffer, zeroed by the host; bar = kBarWords words, zeroed
+__global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                       float* __restrict__ y, float* hx, unsigned* bar,
+                                                       const int* __restrict__ off, const int* __restrict__ len, int B,
+                                                       int Lmax) {
+  // exactly 64 KB; the 16-column block index is XOR-swizzled with the row's lane group so the four lane groups of a wave
+  // (rows 4 kq + r) write different banks
+  __shared__ float red[kWaves][kMaxB][4 * kUnits];
+  const int dir = blockIdx.x % kXcds, blk = blockIdx.x / kXcds;
+  if (dir > 1 || blk >= kBlocksPerDir) return;             // the other XCDs' blocks have nothing to do
+  const int unit0 = blk * kUnits;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int kbase = 4 * kKL * wave + kKL * kq;            // this lane's kKL consecutive k (same mapping for A and B)
+  const unsigned my_xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;
+  if (blk == 0 && tid == 0) bar[4 + dir] = my_xcc + 1u;        // 0 = never written
+  // B fragments: n-tile g = gate g, column n = unit n of this block
+  float wreg[4][kKL];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* wrow = whh + ((size_t)dir * 4 * kH + (size_t)g * kH + unit0 + n) * kH + kbase;
+#pragma unroll
+    for (int s4 = 0; s4 < kKL / 4; ++s4) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * s4);
+      wreg[g][4 * s4] = v.x; wreg[g][4 * s4 + 1] = v.y; wreg[g][4 * s4 + 2] = v.z; wreg[g][4 * s4 + 3] = v.w;
+    }
+  }
+  // cell owner: thread tid -> utterance tid >> 4, unit tid & 15 (32 x 16 = 512 = one cell per thread)
+  const int cb = tid >> 4, cu = tid & 15;
+  const bool own = cb < B;
+  const int my_off = own ? off[cb] : 0, my_len = own ? len[cb] : 0;
+  float c_state = 0.f, h_state = 0.f;
+  float* const hdir = hx + (size_t)dir * 2 * kMaxB * kH;
+  const bool two_tiles = B > 16;
+
+  // gate pre-activations of the input projection for step t are fetched during step t-1 (HBM latency off the chain)
+  float gpre[4] = {0.f, 0.f, 0.f, 0.f};
+  int frame = 0;
+  bool live = false;
+  auto fetch_gx = [&](int t) {
+    live = t < my_len;
+    frame = live ? my_off + (dir == 0 ? t : my_len - 1 - t) : 0;
+    const float* gp = gx + (size_t)frame * (8 * kH) + (size_t)dir * 4 * kH + unit0 + cu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gpre[g] = live ? gp[g * kH] : 0.f;
+  };
+  fetch_gx(0);
+
+  for (int t = 0; t < Lmax; ++t) {
+    const float* hprev = hdir + (size_t)(t & 1) * kMaxB * kH;
+    float* hnext = hdir + (size_t)((t & 1) ^ 1) * kMaxB * kH;
+    // previous h of utterance rows n and n + 16
+    f32x4 ha[kKL / 4], hb[kKL / 4];
+    {
+      const float* a0 = hprev + (size_t)n * kH + kbase;
+      load16_l2(a0, ha[0], ha[1], ha[2], ha[3]);
+      if (two_tiles) {
+        load16_l2(a0 + 16 * kH, hb[0], hb[1], hb[2], hb[3]);
+      } else {
+#pragma unroll
+        for (int s4 = 0; s4 < kKL / 4; ++s4) hb[s4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s4 = 0; s4 < kKL / 4; ++s4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s4][e], wreg[g][4 * s4 + e], acc[0][g], 0, 0, 0);
+        if (two_tiles) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[s4][e], wreg[g][4 * s4 + e], acc[1][g], 0, 0, 0);
+        }
+      }
+    }
+    // D[i][j]: j = lane & 15 (unit), i = 4 * (lane >> 4) + r (utterance within the tile); column g*16 + unit
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[wave][4 * kq + r][((g ^ kq) * kUnits) + n] = acc[0][g][r];
+        red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r];
+      }
+    __syncthreads();
+    if (own) {
+      if (live) {
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = (g ^ ((cb >> 2) & 3)) * kUnits + cu;
+          float a = gpre[g];
+#pragma unroll
+          for (int w = 0; w < kWaves; ++w) a += red[w][cb][col];
+          pre[g] = a;
+        }
+        c_state = sigmoidf_(pre[1]) * c_state + sigmoidf_(pre[0]) * tanhf(pre[2]);
+        h_state = sigmoidf_(pre[3]) * tanhf(c_state);
+        y[(size_t)frame * (2 * kH) + (size_t)dir * kH + unit0 + cu] = h_state;
+      }
+      hnext[(size_t)cb * kH + unit0 + cu] = h_state;        // finished utterances keep publishing their last h (unused)
+    }
+    // step barrier among the 32 blocks of this direction: stores acknowledged by the L2, count in, spin (bounded)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < Lmax) fetch_gx(t + 1);                       // in flight across the barrier
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(&bar[dir], 1u);
+      const unsigned want = (unsigned)kBlocksPerDir * (unsigned)(t + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(&bar[dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spins > (1u << 22)) { bar[2] = 1u; break; }      // a lost block must not hang the GPU: flag it and go on
+        __builtin_amdgcn_s_sleep(1);
+      }
+      // every block of a direction must sit on the same XCD, or the exchange above is not coherent
+      if (t == 0 && __hip_atomic_load(&bar[4 + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc + 1u) bar[2] = 2u;
+    }
+    __syncthreads();
+  }
+}
+
+// a2[row] = relu(sigmoid(y[row] . w + b) * smooth - noise); one wave per row
+__global__ __launch_bounds__(256) void alpha2_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ w, float b,
+                                                     float smooth, float noise, float* __restrict__ a2, int rows, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* yr = y + (size_t)row * ldy;
+  float acc = 0.f;
+  for (int c = 4 * lane; c < D; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(yr + c);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    acc += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) a2[row] = fmaxf(sigmoidf_(acc + b) * smooth - noise, 0.f);
+}
+
+// per utterance: rescale a2 so that it sums to token_num, then cif_wo_hidden(threshold): peaks[t] = integrate after
+// adding alpha[t]; a fire subtracts the threshold.  One block per utterance; the scan is serial from LDS.
+__global__ __launch_bounds__(256) void us_cif_kernel(const float* __restrict__ a2, const int* __restrict__ off,
+                                                     const int* __restrict__ len, const int* __restrict__ token_num,
+                                                     float threshold, float* __restrict__ us_alphas, float* __restrict__ us_peaks) {
+  extern __shared__ float sh[];
+  __shared__ float part[256];
+  const int b = blockIdx.x, L = len[b], o = off[b], tid = threadIdx.x;
+  // left-to-right fp32 sum in 256 interleaved lanes then a serial combine: order differs from torch.sum only in rounding
+  float s = 0.f;
+  for (int t = tid; t < L; t += 256) { const float v = a2[o + t]; sh[t] = v; s += v; }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 256; ++i) tot += part[i];
+    part[0] = (float)token_num[b] / tot;
+  }
+  __syncthreads();
+  const float scale = part[0];
+  for (int t = tid; t < L; t += 256) { const float v = sh[t] * scale; sh[t] = v; us_alphas[o + t] = v; }
+  __syncthreads();
+  if (tid == 0) {
+    float integrate = 0.f;
+    for (int t = 0; t < L; ++t) {
+      integrate += sh[t];
+      us_peaks[o + t] = integrate;
+      if (integrate >= threshold) integrate -= threshold;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_blstm(const float* gx, const float* whh, float* y, float* hx, const int* off, const int* len, int B, int Lmax,
+                        hipStream_t s) {
+  if (B <= 0 || Lmax <= 0) return hipSuccess;
+  if (B > kMaxB) return hipErrorInvalidValue;
+  // hx: exchange buffer, then kBarWords words of barrier state; the error flag (word 2) survives across launches
+  hipError_t e = hipMemsetAsync(hx, 0, (size_t)2 * 2 * kMaxB * kH * sizeof(float) + 2 * sizeof(unsigned), s);
+  if (e != hipSuccess) return e;
+  unsigned* bar = reinterpret_cast<unsigned*>(hx + (size_t)2 * 2 * kMaxB * kH);
+  e = hipMemsetAsync(bar, 0, 2 * sizeof(unsigned), s);
+  if (e != hipSuccess) return e;
+  // one block per (XCD, slot): blocks 8 i + d land on XCD d; only d = 0, 1 work, the rest return at once
+  hipLaunchKernelGGL(blstm_kernel, dim3(kXcds * kBlocksPerDir), dim3(kBlstmThreads), 0, s, gx, whh, y, hx, bar, off, len, B, Lmax);
+  return hipGetLastError();
+}
+
+void launch_alpha2(const float* y, int ldy, const float* w, float b, float smooth, float noise, float* a2, int rows, int D,
+                   hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(alpha2_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, ldy, w, b, smooth, noise, a2, rows, D);
+}
+
+void launch_us_cif(const float* a2, const int* off, const int* len, const int* token_num, int B, int max_len, float threshold,
+                   float* us_alphas, float* us_peaks, hipStream_t s) {
+  if (B <= 0 || max_len <= 0) return;
+  hipLaunchKernelGGL(us_cif_kernel, dim3(B), dim3(256), (size_t)max_len * sizeof(float), s, a2, off, len, token_num, threshold,
+                     us_alphas, us_peaks);
+}
+
+}  // namespace pfhip

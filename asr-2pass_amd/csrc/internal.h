@@ -61,7 +61,8 @@ struct Tensor {
 
 struct Config {
   int d_model = 512, n_head = 4, ffn = 2048, enc_layers = 50, dec_layers = 16, dec_ffn = 2048;
-  int kernel = 11, vocab = 8404, n_mels = 80, lfr_m = 7, lfr_n = 6, pred_residual = 0, contextual = 0;
+  int kernel = 11, vocab = 8404, n_mels = 80, lfr_m = 7, lfr_n = 6, pred_residual = 0, contextual = 0, timestamp = 0;
+  float smooth_factor2 = 0.25f, noise_threshold2 = 0.01f;      // CifPredictorV3 timestamp head
   float cif_threshold = 1.0f, tail_threshold = 0.45f, smooth_factor = 1.0f, noise_threshold = 0.0f;
   int sample_rate = 16000;
 };
@@ -117,6 +118,9 @@ struct pfhip_model {
   float* d_w0qkv = nullptr;     // enc.0.qkv.w K-padded to feat_pad
   float* d_predconv = nullptr;  // [d][3*d] im2col order
   float* d_vocab_bias = nullptr;  // dec.out.b padded to vocab_pad
+  // timestamp head repacks: ConvTranspose1d as [3d][d] + tiled bias, both LSTM directions' input weights [8d][d] + summed
+  // biases, recurrent weights [2][4d][d]
+  float* d_up_w = nullptr; float* d_up_b = nullptr; float* d_wih = nullptr; float* d_bih = nullptr; float* d_whh = nullptr;
   // front-end tables
   float* d_window = nullptr; double* d_tw = nullptr; int* d_mel_off = nullptr; int* d_mel_size = nullptr;
   float* d_mel_w = nullptr; float* d_inv_ts = nullptr;
@@ -124,6 +128,9 @@ struct pfhip_model {
   // workspace
   Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
   Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw;
+  Buf ts_up, ts_gx, ts_y, ts_hx, ts_a2, ts_alphas, ts_peaks, ts_meta;
+  bool have_ts = false;
+  float out2_b = 0.f;
   int n_hw = 0;                  // hotword embeddings resident in `hw` ([n_hw, d])
   void* h_meta = nullptr; size_t h_meta_cap = 0;     // pinned
   int* h_counts = nullptr;                            // pinned [2*B]

@@ -78,6 +78,20 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
                              const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
                              const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s);
 
+// ---- timestamp head (SURVEY §8a row a6 producer; blstm.hip) -------------------------------------------------------
+// Bidirectional LSTM, hidden 512, over packed sequences (off/len in frames, B <= 32): gx [rows, 4096] = input projections
+// + biases (forward i,f,g,o | backward i,f,g,o), whh [2][2048][512], y [rows, 1024]; hx = kBlstmScratchFloats floats of
+// scratch, ZEROED ONCE by the caller; its word kBlstmFlagWord is an error flag the kernel sets (1 = step barrier timed
+// out, 2 = the blocks of a direction were not all on one XCD) — check it after the stream has drained.
+constexpr int kBlstmScratchFloats = 2 * 2 * 32 * 512 + 8;
+constexpr int kBlstmFlagWord = 2 * 2 * 32 * 512 + 2;
+hipError_t launch_blstm(const float* gx, const float* whh, float* y, float* hx, const int* off, const int* len, int B, int Lmax,
+                        hipStream_t s);
+void launch_alpha2(const float* y, int ldy, const float* w, float b, float smooth, float noise, float* a2, int rows, int D,
+                   hipStream_t s);
+void launch_us_cif(const float* a2, const int* off, const int* len, const int* token_num, int B, int max_len, float threshold,
+                   float* us_alphas, float* us_peaks, hipStream_t s);
+
 // ---- predictor / CIF (SURVEY §8a rows a4,a12) -------------------------------------------------
 // col[row] = [h[t-1] | h[t] | h[t+1]] with zeros outside the utterance.  row_pos/row_len give the
 // local index and utterance length of every packed row.

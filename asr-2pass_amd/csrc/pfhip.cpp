@@ -138,6 +138,11 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   c.lfr_n = (int)jc->number("lfr_n", c.lfr_n);
   c.pred_residual = (int)jc->number("pred_residual", 0);
   c.contextual = (int)jc->number("contextual", 0);
+  c.timestamp = (int)jc->number("timestamp", 0);
+  c.smooth_factor2 = (float)jc->number("smooth_factor2", c.smooth_factor2);
+  c.noise_threshold2 = (float)jc->number("noise_threshold2", c.noise_threshold2);
+  if (c.timestamp && (int)jc->number("upsample_times", 3) != 3)
+    return fail(PFHIP_ERR_UNSUPPORTED, "timestamp head: upsample_times must be 3");
   c.cif_threshold = (float)jc->number("cif_threshold", c.cif_threshold);
   c.tail_threshold = (float)jc->number("tail_threshold", c.tail_threshold);
   c.smooth_factor = (float)jc->number("smooth_factor", c.smooth_factor);
@@ -216,6 +221,12 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
          need("bias.dec.kv.w", {2 * d, d}) && need("bias.dec.kv.b", {2 * d}) && need("bias.dec.out.w", {d, d}) &&
          need("bias.dec.out.b", {d}) && need("bias.out.w", {d, 2 * d});
   }
+  if (ok && c.timestamp) {      // CifPredictorV3 upsampling head (SURVEY §8a row a6 producer, appendix A)
+    ok = need("pred.up.w", {d, d, 3}) && need("pred.up.b", {d}) && need("pred.out2.w", {1, 2 * d}) && need("pred.out2.b", {1});
+    for (const char* sfx : {"", "_r"})
+      ok = ok && need(std::string("pred.blstm.w_ih") + sfx, {4 * d, d}) && need(std::string("pred.blstm.w_hh") + sfx, {4 * d, d}) &&
+           need(std::string("pred.blstm.b_ih") + sfx, {4 * d}) && need(std::string("pred.blstm.b_hh") + sfx, {4 * d});
+  }
   if (!ok) return PFHIP_ERR_FORMAT;
 
   // ---- repacks ---------------------------------------------------------------------------------------
@@ -237,6 +248,34 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     std::memcpy(vb.data(), m->W("dec.out.b").h, sizeof(float) * c.vocab);
     st = upload(&m->d_vocab_bias, vb);
     if (st) return st;
+  }
+  if (c.timestamp) {
+    // ConvTranspose1d(d, d, k = stride = 3): out[3t + j][co] = b[co] + sum_ci x[t][ci] * w[ci][co][j]  ==  one GEMM with
+    // the weight laid out [j*d + co][ci]; its [T, 3d] result IS the [3T, d] upsampled sequence.
+    const Tensor& uw = m->W("pred.up.w");
+    std::vector<float> w2((size_t)3 * d * d), b2((size_t)3 * d);
+    for (int ci = 0; ci < d; ++ci)
+      for (int co = 0; co < d; ++co)
+        for (int j = 0; j < 3; ++j) w2[((size_t)j * d + co) * d + ci] = uw.h[((size_t)ci * d + co) * 3 + j];
+    for (int j = 0; j < 3; ++j) std::memcpy(&b2[(size_t)j * d], m->W("pred.up.b").h, sizeof(float) * d);
+    pfhip_status st = upload(&m->d_up_w, w2);
+    if (!st) st = upload(&m->d_up_b, b2);
+    // both directions' input projections in one GEMM (N = 8d), b_ih + b_hh folded; recurrent weights [2][4d][d]
+    std::vector<float> wih((size_t)8 * d * d), bih((size_t)8 * d), whh((size_t)8 * d * d);
+    int dir = 0;
+    for (const char* sfx : {"", "_r"}) {
+      std::memcpy(&wih[(size_t)dir * 4 * d * d], m->W(std::string("pred.blstm.w_ih") + sfx).h, sizeof(float) * 4 * d * d);
+      std::memcpy(&whh[(size_t)dir * 4 * d * d], m->W(std::string("pred.blstm.w_hh") + sfx).h, sizeof(float) * 4 * d * d);
+      const float* bi = m->W(std::string("pred.blstm.b_ih") + sfx).h;
+      const float* bh = m->W(std::string("pred.blstm.b_hh") + sfx).h;
+      for (int k = 0; k < 4 * d; ++k) bih[(size_t)dir * 4 * d + k] = bi[k] + bh[k];
+      ++dir;
+    }
+    if (!st) st = upload(&m->d_wih, wih);
+    if (!st) st = upload(&m->d_bih, bih);
+    if (!st) st = upload(&m->d_whh, whh);
+    if (st) return st;
+    m->out2_b = m->W("pred.out2.b").h[0];
   }
   // ---- front-end tables ------------------------------------------------------------------------------
   {
@@ -274,7 +313,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   const Config& c = m->cfg;
   const int d = c.d_model, FD = m->feat_dim, FP = m->feat_pad;
   HIP_TRY(hipSetDevice(m->device));
-  m->B = B; m->M = 0; m->ML = 0; m->maxT = 0; m->maxL = 0; m->have_logp = false;
+  m->B = B; m->M = 0; m->ML = 0; m->maxT = 0; m->maxL = 0; m->have_logp = false; m->have_ts = false;
   m->T.assign(B, 0); m->row_off.assign(B, 0); m->n_fires.assign(B, 0); m->token_num.assign(B, 0); m->tok_off.assign(B, 0);
   std::vector<int> F(B), frame_off(B + 1, 0);
   for (int b = 0; b < B; ++b) {
@@ -520,6 +559,64 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   return PFHIP_OK;
 }
 
+// ---- a6 producer: CifPredictorV3.get_upsample_timestmap on the encoder output of the batch just run -------------------
+pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
+  const Config& c = m->cfg;
+  if (!c.timestamp) return fail(PFHIP_ERR_UNSUPPORTED, "model has no timestamp head (us_alphas / us_cif_peak outputs)");
+  if (m->have_ts) return PFHIP_OK;
+  const int d = c.d_model, B = m->B, M = m->M;
+  if (M == 0) { m->have_ts = true; return PFHIP_OK; }
+  const int Mp = round_up(M, pfhip::kTileM), R = 3 * M, Rp = 3 * Mp;
+  HIP_TRY(m->ts_up.ensure((size_t)Rp * d * 4));
+  HIP_TRY(m->ts_gx.ensure((size_t)Rp * 8 * d * 4));
+  HIP_TRY(m->ts_y.ensure((size_t)Rp * 2 * d * 4));
+  if (m->ts_hx.cap < (size_t)pfhip::kBlstmScratchFloats * 4) {
+    HIP_TRY(m->ts_hx.ensure((size_t)pfhip::kBlstmScratchFloats * 4));
+    HIP_TRY(hipMemsetAsync(m->ts_hx.p, 0, (size_t)pfhip::kBlstmScratchFloats * 4, s));
+  }
+  HIP_TRY(m->ts_a2.ensure((size_t)R * 4));
+  HIP_TRY(m->ts_alphas.ensure((size_t)R * 4));
+  HIP_TRY(m->ts_peaks.ensure((size_t)R * 4));
+  // upsampled offsets / lengths / token counts per utterance
+  HIP_TRY(m->ts_meta.ensure((size_t)3 * B * 4));
+  std::vector<int> hm((size_t)3 * B);
+  int maxL = 0;
+  for (int b = 0; b < B; ++b) {
+    hm[b] = 3 * m->row_off[b]; hm[B + b] = 3 * m->T[b]; hm[2 * B + b] = m->token_num[b];
+    maxL = std::max(maxL, 3 * m->T[b]);
+  }
+  HIP_TRY(hipMemcpyAsync(m->ts_meta.p, hm.data(), hm.size() * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));          // hm is a stack buffer
+  const int* d_off = m->ts_meta.i();
+  const int* d_len = d_off + B;
+  const int* d_tok = d_off + 2 * B;
+  // ConvTranspose1d: [M, d] x [3d, d]^T -> [M, 3d] == [3M, d]
+  gemm(m, s, m->enc.f(), d, m->d_up_w, 3 * d, d, d, m->ts_up.f(), 3 * d, m->d_up_b, nullptr, 0, nullptr, 0, M, false);
+  // input projections of both directions: [3M, d] x [8d, d]^T -> [3M, 8d]
+  gemm(m, s, m->ts_up.f(), d, m->d_wih, 8 * d, d, d, m->ts_gx.f(), 8 * d, m->d_bih, nullptr, 0, nullptr, 0, R, false);
+  {
+    Scope sc(m, s, K_OTHER, 2.0 * R * 8 * d * d, 4.0 * R * 10 * d);
+    for (int b0 = 0; b0 < B; b0 += 32) {     // the recurrence advances up to 32 utterances together
+      const int nb = std::min(32, B - b0);
+      int lmax = 0;
+      for (int b = b0; b < b0 + nb; ++b) lmax = std::max(lmax, 3 * m->T[b]);
+      HIP_TRY(pfhip::launch_blstm(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), d_off + b0, d_len + b0, nb, lmax, s));
+    }
+    pfhip::launch_alpha2(m->ts_y.f(), 2 * d, m->W("pred.out2.w").d, m->out2_b, c.smooth_factor2, c.noise_threshold2,
+                         m->ts_a2.f(), R, 2 * d, s);
+    pfhip::launch_us_cif(m->ts_a2.f(), d_off, d_len, d_tok, B, maxL, c.cif_threshold - 1e-4f, m->ts_alphas.f(),
+                         m->ts_peaks.f(), s);
+  }
+  HIP_TRY(hipGetLastError());
+  unsigned flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, m->ts_hx.f() + pfhip::kBlstmFlagWord, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (flag) return fail(PFHIP_ERR_HIP, flag == 2 ? "BLSTM: blocks of one direction were not placed on one XCD (results would be incoherent)"
+                                                 : "BLSTM: step barrier timed out");
+  m->have_ts = true;
+  return PFHIP_OK;
+}
+
 pfhip_status head_locked(pfhip_model* m, hipStream_t s, bool want_logp) {
   if (m->ML == 0) return PFHIP_OK;
   const int V = m->cfg.vocab;
@@ -541,6 +638,22 @@ pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
     if (out->token_num) out->token_num[b] = m->token_num[b];
     if (out->n_fires) out->n_fires[b] = m->n_fires[b];
     if (out->n_frames) out->n_frames[b] = m->T[b];
+  }
+  if (out->us_alphas || out->us_peaks || out->us_len) {
+    pfhip_status st = ts_head_locked(m, s);
+    if (st) return st;
+    for (int b = 0; b < B; ++b) {
+      const int L = 3 * m->T[b];
+      if (out->us_len) out->us_len[b] = L;
+      if ((out->us_alphas || out->us_peaks) && out->max_us < L) return fail(PFHIP_ERR_CAPACITY, "max_us smaller than 3 x frames");
+      if (out->us_alphas && L)
+        HIP_TRY(hipMemcpyAsync(out->us_alphas + (size_t)b * out->max_us, m->ts_alphas.f() + (size_t)3 * m->row_off[b], (size_t)L * 4,
+                               hipMemcpyDeviceToHost, s));
+      if (out->us_peaks && L)
+        HIP_TRY(hipMemcpyAsync(out->us_peaks + (size_t)b * out->max_us, m->ts_peaks.f() + (size_t)3 * m->row_off[b], (size_t)L * 4,
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
   }
   if (m->ML == 0) return PFHIP_OK;
   if ((out->token_ids || out->logp) && out->max_tokens < m->maxL)
@@ -625,10 +738,12 @@ void pfhip_destroy(pfhip_model* m) {
   (void)hipDeviceSynchronize();
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
-                 &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw})
+                 &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
-                  (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts})
+                  (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
+                  (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_counts) (void)hipHostFree(m->h_counts);
@@ -728,7 +843,9 @@ static pfhip_status forward_batched(pfhip_model* m, const float* const* pcm, con
       std::vector<int32_t> ids((size_t)utts * max_tok), tn(utts), nf(utts), fr(utts);
       std::vector<float> logp;
       if (want_logp) logp.resize((size_t)utts * max_tok * V);
-      pfhip_out all{ids.data(), tn.data(), nf.data(), fr.data(), want_logp ? logp.data() : nullptr, max_tok};
+      pfhip_out all{};
+      all.token_ids = ids.data(); all.token_num = tn.data(); all.n_fires = nf.data(); all.n_frames = fr.data();
+      all.logp = want_logp ? logp.data() : nullptr; all.max_tokens = max_tok;
       pfhip_status st = forward_direct(m, ptrs.data(), lens.data(), utts, nullptr, 0, &all);
       const std::string err = g_err;
       int u0 = 0;
@@ -766,7 +883,8 @@ pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, cons
   if (!m || !pcm || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
   for (int i = 0; i < batch; ++i)
     if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
-  if (m->batch_wait_us > 0 && !m->cfg.contextual && batch < m->batch_max_utts) return forward_batched(m, pcm, n_samples, batch, out);
+  if (m->batch_wait_us > 0 && !m->cfg.contextual && !m->cfg.timestamp && batch < m->batch_max_utts)
+    return forward_batched(m, pcm, n_samples, batch, out);
   return forward_direct(m, pcm, n_samples, batch, hw_emb, n_hotwords, out);
 }
 
@@ -868,6 +986,9 @@ pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size
   else if (nm == "enc") { src = m->enc.p; n = (size_t)m->M * d; }
   else if (nm == "alphas") { src = m->alphas.p; n = (size_t)m->M; }
   else if (nm == "emb") { src = m->emb.p; n = (size_t)m->ML * d; }
+  else if (nm == "ts_up" && m->have_ts) { src = m->ts_up.p; n = (size_t)3 * m->M * d; }            // timestamp-head stages
+  else if (nm == "ts_gx" && m->have_ts) { src = m->ts_gx.p; n = (size_t)3 * m->M * 8 * d; }
+  else if (nm == "ts_y" && m->have_ts) { src = m->ts_y.p; n = (size_t)3 * m->M * 2 * d; }
   else if (nm == "logp") {
     if (m->ML && !m->have_logp) { pfhip_status st = head_locked(m, s, true); if (st) return st; }
     src = m->logp.p; n = (size_t)m->ML * m->cfg.vocab;

@@ -88,6 +88,18 @@ def tensor_specs(cfg):
     lin("dec3.ffn2", d, fd, bias=False)
     ln("dec.after_norm", d)
     lin("dec.out", V, d)
+    if cfg.get("timestamp", 0):
+        # CifPredictorV3 timestamp head (UPSTREAM bicif_paraformer, upsample_type cnn_blstm): ConvTranspose1d(d, d, k=3,
+        # stride=3) -> BLSTM(d, d) -> Linear(2d, 1); torch layouts ([in, out, k]; gates i,f,g,o; *_r = reverse direction)
+        specs.append(("pred.up.w", [d, d, 3], ("normal", 1.0 / math.sqrt(d))))
+        specs.append(("pred.up.b", [d], ("normal", 0.02)))
+        for sfx in ("", "_r"):
+            specs.append((f"pred.blstm.w_ih{sfx}", [4 * d, d], ("normal", 1.0 / math.sqrt(d))))
+            specs.append((f"pred.blstm.w_hh{sfx}", [4 * d, d], ("normal", 1.0 / math.sqrt(d))))
+            specs.append((f"pred.blstm.b_ih{sfx}", [4 * d], ("normal", 0.1)))
+            specs.append((f"pred.blstm.b_hh{sfx}", [4 * d], ("normal", 0.1)))
+        specs.append(("pred.out2.w", [1, 2 * d], ("normal", 1.0 / math.sqrt(2 * d))))
+        specs.append(("pred.out2.b", [1], ("const", 0.3)))
     if cfg.get("contextual", 0):
         # hotword embedder (model_eb.onnx: Embedding + 1-layer LSTM) and the bias decoder of the last layer
         specs.append(("bias.embed.w", [V, d], ("normal", 1.0)))

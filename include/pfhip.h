@@ -76,6 +76,13 @@ typedef struct {
   int32_t* n_frames;
   float* logp;
   int32_t max_tokens;
+  /* Timestamp models only (the reference's 4-output graph, paraformer.cpp:545-562 `outputTensor.size() == 4`): the
+   * x3-upsampled alphas and CIF integrate trace that TimestampOnnx consumes (pfhip_timestamp_onnx below), one row of
+   * max_us floats per utterance, us_len[b] = 3 * n_frames[b] valid.  Any of the three may be NULL; all NULL = skip. */
+  float* us_alphas;
+  float* us_peaks;
+  int32_t* us_len;
+  int32_t max_us;
 } pfhip_out;
 
 /* Host-buffer form: pcm[i] points at n_samples[i] floats in [-1,1) exactly as Model::Forward gets

@@ -220,6 +220,60 @@ def hotword_embed(hotword_matrix, lengths, W):
     return out
 
 
+def _lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of torch.nn.LSTM (gates i,f,g,o) over x [L, d]; returns h for every step [L, H]."""
+    L = x.shape[0]
+    H = w_hh.shape[1]
+    gx = (x @ w_ih.T + (b_ih + b_hh)).astype(F32)
+    h = np.zeros(H, F32)
+    c = np.zeros(H, F32)
+    out = np.zeros((L, H), F32)
+    sig = lambda z: (F32(1) / (F32(1) + np.exp(-z))).astype(F32)
+    for t in (range(L - 1, -1, -1) if reverse else range(L)):
+        g = (gx[t] + w_hh @ h).astype(F32)
+        i_, f_, g_, o_ = g[:H], g[H:2 * H], g[2 * H:3 * H], g[3 * H:]
+        c = (sig(f_) * c + sig(i_) * np.tanh(g_)).astype(F32)
+        h = (sig(o_) * np.tanh(c)).astype(F32)
+        out[t] = h
+    return out
+
+
+def cif_wo_hidden(alphas, threshold):
+    """UPSTREAM cif_wo_hidden: the integrate value after each frame's alpha is added (before a fire is subtracted)."""
+    integrate = F32(0)
+    out = np.zeros(len(alphas), F32)
+    for t, a in enumerate(alphas):
+        integrate = F32(integrate + F32(a))
+        out[t] = integrate
+        if integrate >= F32(threshold):
+            integrate = F32(integrate - F32(threshold))
+    return out
+
+
+def timestamp_head(enc, token_num, W):
+    """CifPredictorV3.get_upsample_timestmap as exported for the timestamp model (SURVEY §8 row a6 producer; UPSTREAM,
+    parity unpinned): enc [T, d] -> (us_alphas [3T], us_cif_peak [3T]), the two extra outputs Paraformer::Forward hands to
+    TimestampOnnx (paraformer.cpp:545-562).  ConvTranspose1d(k = stride = 3) -> BLSTM -> Linear -> sigmoid ->
+    relu(a * smooth_factor2 - noise_threshold2), rescaled so that it sums to token_num, then cif_wo_hidden(threshold - 1e-4)."""
+    cfg = W.cfg
+    T, d = enc.shape
+    up = int(cfg.get("upsample_times", 3))
+    wt = W["pred.up.w"]                                         # [ci, co, k]
+    u = np.zeros((T, up, d), F32)
+    for j in range(up):
+        u[:, j, :] = (enc @ wt[:, :, j] + W["pred.up.b"]).astype(F32)      # out[3t + j] = x[t] @ W[:, :, j] + b
+    u = u.reshape(T * up, d)
+    hf = _lstm_dir(u, W["pred.blstm.w_ih"], W["pred.blstm.w_hh"], W["pred.blstm.b_ih"], W["pred.blstm.b_hh"], False)
+    hb = _lstm_dir(u, W["pred.blstm.w_ih_r"], W["pred.blstm.w_hh_r"], W["pred.blstm.b_ih_r"], W["pred.blstm.b_hh_r"], True)
+    y = np.concatenate([hf, hb], axis=1)
+    z = (y @ W["pred.out2.w"].reshape(-1) + W["pred.out2.b"][0]).astype(F32)
+    a2 = (F32(1) / (F32(1) + np.exp(-z))).astype(F32)
+    a2 = np.maximum(a2 * F32(cfg.get("smooth_factor2", 0.25)) - F32(cfg.get("noise_threshold2", 0.01)), F32(0)).astype(F32)
+    total = F32(np.cumsum(a2, dtype=F32)[-1])
+    us_alphas = (a2 * (F32(token_num) / total)).astype(F32)
+    return us_alphas, cif_wo_hidden(us_alphas, F32(cfg["cif_threshold"]) - F32(1e-4))
+
+
 def contextual_last_layer(x, mem, hw_emb, W, pfx, n_head):
     """UPSTREAM ContextualDecoderLayer + ContextualBiasDecoder + bias_output: the last decoder
     layer's cross-attention output is concatenated with a cross-attention over the hotword embeddings and projected

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
-    "pfhip_set_batching", "pfhip_is_contextual", "pfhip_hotword_embed", "pfhip_set_hotwords",
+    "pfhip_set_batching", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",

@@ -67,21 +67,40 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
                                                 const std::vector<std::vector<float>>& hw_emb, void* wfst_decoder,
                                                 int batch_in) {
   (void)input_finished;
-  (void)hw_emb;
   (void)wfst_decoder;
   std::vector<std::string> results(batch_in > 0 ? batch_in : 0);
   last_ids_.assign(results.size(), {});
+  last_spans_.assign(results.size(), {});
   if (batch_in <= 0 || !handle_) return results;
   int max_len = 0;
   for (int i = 0; i < batch_in; ++i) max_len = len[i] > max_len ? len[i] : max_len;
   const int max_tokens = max_len / 960 + 2;       // at most T+1 CIF fires, T = ceil(frames/6)
-  std::vector<int32_t> ids((size_t)batch_in * max_tokens), tn(batch_in), nf(batch_in);
+  std::vector<int32_t> ids((size_t)batch_in * max_tokens), tn(batch_in), nf(batch_in), usl(batch_in);
   pfhip_out out{};
   out.token_ids = ids.data();
   out.token_num = tn.data();
   out.n_fires = nf.data();
   out.max_tokens = max_tokens;
-  const pfhip_status st = pfhip_offline_forward(handle_, din, len, batch_in, nullptr, 0, &out);
+  const bool with_ts = pfhip_has_timestamp_head(handle_) != 0;      // the reference's outputTensor.size() == 4 (paraformer.cpp:545)
+  const int max_us = 3 * max_tokens;
+  std::vector<float> usa, usp;
+  if (with_ts) {
+    usa.resize((size_t)batch_in * max_us);
+    usp.resize((size_t)batch_in * max_us);
+    out.us_alphas = usa.data(); out.us_peaks = usp.data(); out.us_len = usl.data(); out.max_us = max_us;
+  }
+  // hw_emb [H][d] as the reference passes it (paraformer.cpp:515-531); plain models ignore it
+  std::vector<float> hw;
+  int n_hw = 0;
+  if (pfhip_is_contextual(handle_)) {
+    const size_t d = (size_t)pfhip_d_model(handle_);
+    for (const auto& row : hw_emb) {
+      if (row.size() != d) continue;
+      hw.insert(hw.end(), row.begin(), row.end());
+      ++n_hw;
+    }
+  }
+  const pfhip_status st = pfhip_offline_forward(handle_, din, len, batch_in, n_hw ? hw.data() : nullptr, n_hw, &out);
   if (st != PFHIP_OK) {
     std::fprintf(stderr, "ParaformerHip::Forward: %s\n", pfhip_last_error());
     return results;                                // "" per item, as paraformer.cpp:582-588
@@ -90,14 +109,64 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
     const int n = tn[i] < nf[i] ? tn[i] : nf[i];
     last_ids_[i].assign(ids.begin() + (size_t)i * max_tokens, ids.begin() + (size_t)i * max_tokens + n);
     results[i] = IdsToString(last_ids_[i]);
+    if (with_ts && n > 0 && usl[i] > 0) {
+      // GreedySearch(..., is_stamp = true) -> TimestampOnnx over the characters of the hypothesis (paraformer.cpp:386-395)
+      std::vector<float> spans((size_t)3 * (2 * n + 2));
+      int n_spans = 0;
+      if (pfhip_timestamp_onnx(usa.data() + (size_t)i * max_us, usp.data() + (size_t)i * max_us, usl[i], n, 0.f, -1.5f,
+                               spans.data(), (int)spans.size() / 3, &n_spans) == PFHIP_OK)
+        last_spans_[i].assign(spans.begin(), spans.begin() + (size_t)3 * n_spans);
+    }
   }
   return results;
 }
 
+namespace {
+// UTF-8 code points of s, one string each
+std::vector<std::string> Utf8Chars(const std::string& s) {
+  std::vector<std::string> out;
+  for (size_t i = 0; i < s.size();) {
+    const unsigned char c = (unsigned char)s[i];
+    const size_t n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 1;
+    out.push_back(s.substr(i, n));
+    i += n;
+  }
+  return out;
+}
+}  // namespace
+
 std::vector<std::vector<float>> ParaformerHip::CompileHotwordEmbedding(std::string& hotwords) {
-  (void)hotwords;
   const int d = handle_ ? pfhip_d_model(handle_) : 512;
-  return {std::vector<float>(d, 0.f)};
+  if (!handle_ || !pfhip_is_contextual(handle_)) return {std::vector<float>(d, 0.f)};      // paraformer.cpp:594-599
+  const int kMaxLen = 10;                                                                 // :629
+  std::vector<int32_t> mat, lens;
+  std::stringstream ss(hotwords);
+  std::string word;
+  while (ss >> word) {
+    std::vector<int32_t> row;
+    bool known = true;
+    for (const std::string& ch : Utf8Chars(word)) {
+      int id = -1;
+      for (size_t t = 0; t < tokens_.size(); ++t)
+        if (tokens_[t] == ch) { id = (int)t; break; }
+      if (id < 0) { known = false; break; }       // the reference drops a hotword with an out-of-vocabulary unit (:634-640)
+      if ((int)row.size() < kMaxLen) row.push_back(id);
+    }
+    if (!known || row.empty()) continue;
+    lens.push_back((int32_t)row.size());
+    row.resize(kMaxLen, 0);
+    mat.insert(mat.end(), row.begin(), row.end());
+  }
+  { std::vector<int32_t> last(kMaxLen, 0); last[0] = 1; mat.insert(mat.end(), last.begin(), last.end()); lens.push_back(1); }   // :648-651
+  const int H = (int)lens.size();
+  std::vector<float> emb((size_t)H * d);
+  if (pfhip_hotword_embed(handle_, mat.data(), lens.data(), H, emb.data()) != PFHIP_OK) {
+    std::fprintf(stderr, "ParaformerHip::CompileHotwordEmbedding: %s\n", pfhip_last_error());
+    return {std::vector<float>(d, 0.f)};
+  }
+  std::vector<std::vector<float>> out(H);
+  for (int i = 0; i < H; ++i) out[i].assign(emb.begin() + (size_t)i * d, emb.begin() + (size_t)(i + 1) * d);
+  return out;
 }
 
 }  // namespace funasr

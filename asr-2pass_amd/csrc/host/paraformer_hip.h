@@ -59,7 +59,10 @@ class ParaformerHip : public ParaformerHipBase {
                                    const std::vector<std::vector<float>>& hw_emb, void* wfst_decoder,
                                    int batch_in) override;
   // Plain model: one zero row of encoder_size, as Paraformer::CompileHotwordEmbedding does when
-  // use_hotword is false (paraformer.cpp:594-599).
+  // use_hotword is false (paraformer.cpp:594-599).  Contextual model: whitespace-separated hotwords, each split into
+  // vocabulary units (UTF-8 characters looked up in tokens.json; the reference additionally consults seg_dict for
+  // Latin words, :601-647 — host text handling, not restated), at most 10 ids each, the [1,0,...] row appended
+  // (:648-651), then the device embedder (pfhip_hotword_embed).
   std::vector<std::vector<float>> CompileHotwordEmbedding(std::string& hotwords) override;
   void StartUtterance() override {}
   void EndUtterance() override {}
@@ -71,6 +74,9 @@ class ParaformerHip : public ParaformerHipBase {
 
   // token ids of the last Forward, per utterance (what GreedySearch computed, paraformer.cpp:386-395)
   const std::vector<std::vector<int>>& LastTokenIds() const { return last_ids_; }
+  // timestamp models: (begin_s, end_s, is_sil) per span of the last Forward, what TimestampOnnx produced
+  // (paraformer.cpp:545-562 + util.cpp:838-963); empty for plain models
+  const std::vector<std::vector<float>>& LastTimestamps() const { return last_spans_; }
   void SetDevice(int device) { device_ = device; }
 
  private:
@@ -80,6 +86,7 @@ class ParaformerHip : public ParaformerHipBase {
   int batch_size_ = 1;
   std::vector<std::string> tokens_;
   std::vector<std::vector<int>> last_ids_;
+  std::vector<std::vector<float>> last_spans_;
 };
 
 }  // namespace funasr

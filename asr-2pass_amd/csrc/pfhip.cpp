@@ -906,6 +906,7 @@ pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwo
 }
 
 int pfhip_is_contextual(const pfhip_model* m) { return m ? m->cfg.contextual : 0; }
+int pfhip_has_timestamp_head(const pfhip_model* m) { return m ? m->cfg.timestamp : 0; }
 
 // model_eb.onnx Run + row selection (paraformer.cpp:656-685): Embedding -> 1-layer LSTM over the 10 padded positions,
 // output of hotword j taken at step lengths[j]-1.

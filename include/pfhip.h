@@ -113,6 +113,8 @@ pfhip_status pfhip_offline_fetch(pfhip_model* m, pfhip_out* out);
  *                           pfhip_offline_forward takes hw_emb [H, d] per call like the reference (paraformer.cpp:515-531).
  * A contextual model without hotwords is an error ("hw_emb is null", :516-520); a plain model ignores them. */
 int pfhip_is_contextual(const pfhip_model* m);
+/* 1 when the model carries the CifPredictorV3 upsampling head (the reference's 4-output graph, paraformer.cpp:545). */
+int pfhip_has_timestamp_head(const pfhip_model* m);
 pfhip_status pfhip_hotword_embed(pfhip_model* m, const int32_t* hotword_matrix, const int32_t* lengths, int n_hotwords,
                                  float* out);
 pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwords);

@@ -1,0 +1,206 @@
+#include "funasrruntime_hip.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <sstream>
+
+#include "paraformer_hip.h"
+
+namespace {
+
+struct OfflineStreamHip {
+  funasr::ParaformerHip asr;
+  pfhip_vad* vad = nullptr;
+  std::mutex vad_mu;            // FsmnVad keeps per-file caches: one file at a time, like the reference's per-call Reset
+  float speech_noise_thres = 0.9f;       // vad.yaml default the reference passes (fsmn-vad.cpp:251-254)
+  ~OfflineStreamHip() { if (vad) pfhip_vad_destroy(vad); }
+};
+
+struct RecogResult {               // funasr::FUNASR_RECOG_RESULT (com-define.h)
+  std::string msg, stamp;
+  float snippet_time = 0.f;
+  std::vector<std::vector<int>> seg_ids;
+  std::vector<std::pair<int, int>> segs;
+};
+
+bool ReadAll(const std::string& path, std::vector<char>& out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  f.seekg(0, std::ios::end);
+  out.resize((size_t)f.tellg());
+  f.seekg(0);
+  f.read(out.data(), (std::streamsize)out.size());
+  return (bool)f;
+}
+
+constexpr int kSegSample = 16;      // samples per ms at 16 kHz (audio.cpp: seg_sample = MODEL_SAMPLE_RATE / 1000)
+
+// Audio::CutSplit (audio.cpp:1172-1240): the FSMN-VAD scores the whole buffer in one pass (it is causal: the reference's
+// 1-s slices carry the same cache state), the end-point detector runs on the host, segments come back in ms.
+bool CutSplit(OfflineStreamHip* os, const std::vector<float>& pcm, int vad_tail_sil, int vad_max_len,
+              std::vector<std::pair<int, int>>& frames, std::vector<int>& index_vector) {
+  frames.clear();
+  index_vector.clear();
+  const int n = (int)pcm.size();
+  const int max_frames = n >= 400 ? (n - 400) / 160 + 1 : 0;
+  if (max_frames <= 0) return true;
+  std::vector<float> sil((size_t)max_frames + 8);
+  int T = 0;
+  std::lock_guard<std::mutex> lk(os->vad_mu);
+  if (pfhip_vad_reset(os->vad) != PFHIP_OK) return false;
+  if (pfhip_vad_forward_sil(os->vad, pcm.data(), n, 1, sil.data(), sil.size(), &T) != PFHIP_OK) return false;
+  if (T <= 0) return true;
+  pfhip_vadseg* seg = nullptr;
+  if (pfhip_vadseg_create(&seg) != PFHIP_OK) return false;
+  const int n_used = 400 + 160 * (T - 1);
+  std::vector<int32_t> pairs((size_t)2 * (T / 2 + 8));
+  int n_seg = 0;
+  const pfhip_status st = pfhip_vadseg_feed(seg, sil.data(), T, pcm.data(), std::min(n_used, n), 1, 0, vad_tail_sil, vad_max_len,
+                                            os->speech_noise_thres, 16000, pairs.data(), (int)pairs.size() / 2, &n_seg);
+  pfhip_vadseg_destroy(seg);
+  if (st != PFHIP_OK) return false;
+  for (int i = 0; i < n_seg; ++i)
+    frames.emplace_back(pairs[2 * i] * kSegSample, std::min(pairs[2 * i + 1] * kSegSample, n));
+  index_vector.resize(frames.size());
+  std::iota(index_vector.begin(), index_vector.end(), 0);
+  // audio.cpp:1226-1239: queue by increasing length (ties keep time order)
+  std::stable_sort(index_vector.begin(), index_vector.end(), [&](int a, int b) {
+    return frames[a].second - frames[a].first < frames[b].second - frames[b].first;
+  });
+  return true;
+}
+
+// Audio::FetchDynamic (audio.cpp:1052-1108): pops one batch off the front of `queue` (positions into `order`)
+int FetchDynamic(const std::vector<std::pair<int, int>>& frames, const std::vector<int>& order, size_t& head, int batch_size,
+                 std::vector<int>& batch) {
+  const long max_acc = 300L * 1000 * kSegSample, max_sent = 60L * 1000 * kSegSample;
+  batch.clear();
+  long bs_acc = 0, max_len = 0;
+  const int max_batch = (int)std::min<size_t>((size_t)batch_size, order.size() - head);
+  for (int i = 0; i < max_batch; ++i) {
+    const auto& fr = frames[order[head]];
+    const long length = fr.second - fr.first;
+    if (length >= max_sent) {
+      if (bs_acc == 0) { ++bs_acc; batch.push_back(order[head++]); }
+      break;
+    }
+    max_len = std::max(max_len, length);
+    if (max_len * (bs_acc + 1) > max_acc) break;
+    ++bs_acc;
+    batch.push_back(order[head++]);
+  }
+  return (int)batch.size();
+}
+
+}  // namespace
+
+FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int thread_num, bool use_gpu, int batch_size) {
+  (void)use_gpu;                         // there is no CPU path
+  auto os = std::make_unique<OfflineStreamHip>();
+  const std::string dir = model_path[MODEL_DIR];
+  std::string tok = model_path.count(TOKEN_PATH) ? model_path[TOKEN_PATH] : dir + "/tokens.json";
+  { std::ifstream probe(tok); if (!probe) tok.clear(); }
+  os->asr.InitAsr(dir + "/model.pfhip.bin", "", dir + "/model.pfhip.json", tok, thread_num);      // exits on failure
+  os->asr.SetBatchSize(batch_size);
+  if (model_path.count(VAD_DIR) && !model_path[VAD_DIR].empty()) {
+    std::vector<char> blob, man;
+    if (!ReadAll(model_path[VAD_DIR] + "/vad.pfhip.bin", blob) || !ReadAll(model_path[VAD_DIR] + "/vad.pfhip.json", man)) {
+      std::fprintf(stderr, "Error when load vad hip model: cannot read %s\n", model_path[VAD_DIR].c_str());
+      std::exit(-1);                     // fsmn-vad.cpp:30-33
+    }
+    man.push_back('\0');
+    if (pfhip_vad_create_from_memory(blob.data(), blob.size(), man.data(), 0, &os->vad) != PFHIP_OK) {
+      std::fprintf(stderr, "Error when load vad hip model: %s\n", pfhip_last_error());
+      std::exit(-1);
+    }
+  }
+  return os.release();
+}
+
+FUNASR_RESULT FunOfflineInferBuffer(FUNASR_HANDLE handle, const char* sz_buf, int n_len, FUNASR_MODE mode, QM_CALLBACK fn_callback,
+                                    const std::vector<std::vector<float>>& hw_emb, int sampling_rate, std::string wav_format,
+                                    bool itn, int vad_tail_sil, int vad_max_len, FUNASR_DEC_HANDLE dec_handle) {
+  (void)mode; (void)itn; (void)dec_handle;
+  OfflineStreamHip* os = static_cast<OfflineStreamHip*>(handle);
+  if (!os || !sz_buf) return nullptr;
+  if (wav_format != "pcm" && wav_format != "PCM") return nullptr;      // the reference decodes other containers with ffmpeg
+  if (sampling_rate != os->asr.GetAsrSampleRate()) return nullptr;     // resampling (audio.cpp:230-260) is caller-side here
+  // Audio::LoadPcmwav (audio.cpp:787-819): s16 LE -> f32 / 32768
+  const int n = n_len / 2;
+  std::vector<float> pcm((size_t)n);
+  const int16_t* s16 = reinterpret_cast<const int16_t*>(sz_buf);
+  for (int i = 0; i < n; ++i) pcm[i] = (float)s16[i] / 32768.f;
+  auto res = std::make_unique<RecogResult>();
+  res->snippet_time = (float)n / (float)sampling_rate;
+  if (n == 0) return res.release();
+  std::vector<int> index_vector = {0};
+  res->segs.assign(1, {0, n});
+  if (os->vad) {
+    if (!CutSplit(os, pcm, vad_tail_sil, vad_max_len, res->segs, index_vector)) {
+      std::fprintf(stderr, "FunOfflineInferBuffer: %s\n", pfhip_last_error());
+      return res.release();
+    }
+  }
+  std::vector<std::string> msgs(index_vector.size());
+  std::vector<std::vector<float>> spans(index_vector.size());
+  res->seg_ids.assign(index_vector.size(), {});
+  size_t head = 0, msg_idx = 0;
+  std::vector<int> batch;
+  const int batch_size = os->asr.GetBatchSize();
+  int step = 0;
+  while (FetchDynamic(res->segs, index_vector, head, batch_size, batch) > 0) {
+    std::vector<float*> buff(batch.size());
+    std::vector<int> len(batch.size());
+    for (size_t k = 0; k < batch.size(); ++k) {
+      buff[k] = pcm.data() + res->segs[batch[k]].first;
+      len[k] = res->segs[batch[k]].second - res->segs[batch[k]].first;
+    }
+    const std::vector<std::string> msg_batch = os->asr.Forward(buff.data(), len.data(), true, hw_emb, nullptr, (int)batch.size());
+    for (size_t k = 0; k < batch.size(); ++k, ++msg_idx) {        // funasrruntime.cpp:270-279
+      const int seg = index_vector[msg_idx];
+      msgs[seg] = msg_batch[k];
+      res->seg_ids[seg] = os->asr.LastTokenIds()[k];
+      if (k < os->asr.LastTimestamps().size()) spans[seg] = os->asr.LastTimestamps()[k];
+    }
+    if (fn_callback) fn_callback(++step, (int)index_vector.size());
+  }
+  std::string cur_stamp = "[";
+  for (size_t idx = 0; idx < msgs.size(); ++idx) {
+    if (msgs[idx].empty()) continue;
+    res->msg += msgs[idx];
+    const float t0 = (float)res->segs[idx].first / (float)sampling_rate;                        // msg_stimes
+    for (size_t i = 0; i + 2 < spans[idx].size() + 1 && i + 2 <= spans[idx].size(); i += 3) {      // (begin_s, end_s, is_sil)
+      if (spans[idx][i + 2] != 0.f) continue;                                                   // <sil> spans carry no character
+      cur_stamp += "[" + std::to_string((int)(1000 * (spans[idx][i] + t0))) + "," + std::to_string((int)(1000 * (spans[idx][i + 1] + t0))) + "],";
+    }
+  }
+  if (cur_stamp != "[") {
+    cur_stamp.erase(cur_stamp.size() - 1);
+    res->stamp = cur_stamp + "]";
+  }
+  return res.release();
+}
+
+const std::vector<std::vector<float>> CompileHotwordEmbedding(FUNASR_HANDLE handle, std::string& hotwords, ASR_TYPE mode) {
+  (void)mode;
+  OfflineStreamHip* os = static_cast<OfflineStreamHip*>(handle);
+  if (!os) return {};
+  return os->asr.CompileHotwordEmbedding(hotwords);
+}
+
+const char* FunASRGetResult(FUNASR_RESULT result, int n_index) {
+  (void)n_index;
+  return result ? static_cast<RecogResult*>(result)->msg.c_str() : nullptr;
+}
+const char* FunASRGetStamp(FUNASR_RESULT result) { return result ? static_cast<RecogResult*>(result)->stamp.c_str() : nullptr; }
+float FunASRGetRetSnippetTime(FUNASR_RESULT result) { return result ? static_cast<RecogResult*>(result)->snippet_time : 0.f; }
+void FunASRFreeResult(FUNASR_RESULT result) { delete static_cast<RecogResult*>(result); }
+void FunOfflineUninit(FUNASR_HANDLE handle) { delete static_cast<OfflineStreamHip*>(handle); }
+const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->seg_ids; }
+const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->segs; }

@@ -1,0 +1,52 @@
+// The offline slice of the reference's handle API (onnxruntime/include/funasrruntime.h:69-115), same names, argument
+// meaning and error behaviour, on top of the HIP plug-ins — what the websocket server's decoder threads call
+// (websocket/bin/websocket-server.cpp:81-89,173,209-210):
+//
+//   FunOfflineInit          funasrruntime.cpp:36-40     OfflineStream: VAD + acoustic model (+ batch size)
+//   FunOfflineInferBuffer   funasrruntime.cpp:208-337   LoadPcmwav -> CutSplit -> FetchDynamic -> Model::Forward -> re-ordering
+//   FunASRGetResult / FunASRGetStamp / FunASRGetRetSnippetTime / FunASRFreeResult   funasrruntime.cpp:540-640
+//   CompileHotwordEmbedding funasrruntime.cpp:862-867
+//   FunOfflineUninit        funasrruntime.cpp:806-814
+//
+// Stand-alone mirror: inside the reference tree the real funasrruntime.cpp stays and only the Model classes are swapped
+// (INTEGRATION.md).  What is NOT here is the text side of the reference function: audio container decode (ffmpeg), CT-
+// Transformer text re-segmentation (`AddPunc`, ct-transformer.cpp:39-155), ITN and sentence stamps — SURVEY §8 keeps
+// those above the hot path.  Result text = the vocabulary strings of the greedy tokens (or space-separated ids without
+// a tokens.json); stamps have the reference's "[[b,e],[b,e]...]" millisecond format.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#define MODEL_DIR "model-dir"          // com-define.h:52-60 keys used by the offline path
+#define VAD_DIR "vad-dir"
+#define TOKEN_PATH "token-path"
+
+typedef void* FUNASR_HANDLE;
+typedef void* FUNASR_RESULT;
+typedef void* FUNASR_DEC_HANDLE;
+typedef enum { RASR_NONE = -1, RASRM_CTC_GREEDY_SEARCH = 0 } FUNASR_MODE;      // funasrruntime.h:30-35 (subset)
+typedef enum { ASR_OFFLINE = 0, ASR_ONLINE = 1, ASR_TWO_PASS = 2 } ASR_TYPE;   // funasrruntime.h:48-52
+typedef void (*QM_CALLBACK)(int cur_step, int n_total);
+
+// model_path: MODEL_DIR = directory holding model.pfhip.bin / model.pfhip.json (+ tokens.json unless TOKEN_PATH is given),
+// VAD_DIR = directory holding vad.pfhip.bin / vad.pfhip.json (absent or "" = no VAD: the buffer is one segment).
+// A model that fails to load ends the process like the reference (paraformer.cpp:43-46).
+FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int thread_num, bool use_gpu = true,
+                             int batch_size = 1);
+// sz_buf: n_len BYTES of little-endian int16 PCM (wav_format "pcm"/"PCM"; anything else returns nullptr: the
+// reference would hand it to ffmpeg).  Returns nullptr on a bad handle/format, a result with empty msg for empty audio.
+FUNASR_RESULT FunOfflineInferBuffer(FUNASR_HANDLE handle, const char* sz_buf, int n_len, FUNASR_MODE mode,
+                                    QM_CALLBACK fn_callback, const std::vector<std::vector<float>>& hw_emb,
+                                    int sampling_rate = 16000, std::string wav_format = "pcm", bool itn = true,
+                                    int vad_tail_sil = 800, int vad_max_len = 60000, FUNASR_DEC_HANDLE dec_handle = nullptr);
+const std::vector<std::vector<float>> CompileHotwordEmbedding(FUNASR_HANDLE handle, std::string& hotwords, ASR_TYPE mode = ASR_OFFLINE);
+const char* FunASRGetResult(FUNASR_RESULT result, int n_index);
+const char* FunASRGetStamp(FUNASR_RESULT result);
+float FunASRGetRetSnippetTime(FUNASR_RESULT result);
+void FunASRFreeResult(FUNASR_RESULT result);
+void FunOfflineUninit(FUNASR_HANDLE handle);
+
+// Inspection for tests: token ids per VAD segment in time order and the segments (samples) of the last result.
+const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result);
+const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result);

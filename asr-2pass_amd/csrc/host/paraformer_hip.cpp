@@ -111,9 +111,15 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
     results[i] = IdsToString(last_ids_[i]);
     if (with_ts && n > 0 && usl[i] > 0) {
       // GreedySearch(..., is_stamp = true) -> TimestampOnnx over the characters of the hypothesis (paraformer.cpp:386-395)
+      // char_list = all token_num hypotheses (Vocab::Vector2String keeps every id); TimestampOnnx drops a trailing "</s>"
+      // (util.cpp:846-849) — id 2 in the FunASR vocabularies when no tokens.json is loaded
+      const int last = last_ids_[i].back();
+      const bool eos = tokens_.empty() ? last == 2 : ((size_t)last < tokens_.size() && tokens_[last] == "</s>");
+      const int n_chars = n - (eos ? 1 : 0);
       std::vector<float> spans((size_t)3 * (2 * n + 2));
       int n_spans = 0;
-      if (pfhip_timestamp_onnx(usa.data() + (size_t)i * max_us, usp.data() + (size_t)i * max_us, usl[i], n, 0.f, -1.5f,
+      if (n_chars > 0 &&
+          pfhip_timestamp_onnx(usa.data() + (size_t)i * max_us, usp.data() + (size_t)i * max_us, usl[i], n_chars, 0.f, -1.5f,
                                spans.data(), (int)spans.size() / 3, &n_spans) == PFHIP_OK)
         last_spans_[i].assign(spans.begin(), spans.begin() + (size_t)3 * n_spans);
     }

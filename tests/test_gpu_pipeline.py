@@ -86,3 +86,52 @@ def test_fetch_dynamic_rule(pkg):
     # batch_size cap
     q = [(0, S)] * 10
     assert len(pipeline.fetch_dynamic(q, 4)) == 4
+
+
+def test_cpp_handle_api_matches_python_flow(pkg, weights_mod, tmp_path):
+    """The C++ mirror of FunOfflineInit / FunOfflineInferBuffer / FunASRGetResult (csrc/host/funasrruntime_hip.cpp, run
+    through the `offline_infer` harness on a model directory and an s16 PCM file) gives the same segments and token ids
+    as the Python flow above, for two batch sizes (the dynamic batcher only changes the grouping)."""
+    import json
+    import os
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    pipeline = importlib.import_module("asr_2pass_amd.pipeline")
+    rng = np.random.default_rng(11)
+    pcm = make_file(rng)
+    s16 = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2")
+    pcm = (s16.astype(np.float32) / 32768.0).astype(np.float32)            # what LoadPcmwav makes of the file
+    vman, vblob = shape_vad_weights(*weights_mod.synth_vad_weights())
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=1, vocab=300, timestamp=1)
+    aman, ablob = weights_mod.synth_weights(cfg)
+    mdir, vdir = tmp_path / "asr", tmp_path / "vad"
+    mdir.mkdir(); vdir.mkdir()
+    weights_mod.save(str(mdir / "model.pfhip"), aman, ablob)
+    weights_mod.save(str(vdir / "vad.pfhip"), vman, vblob)
+    with open(mdir / "tokens.json", "w") as f:
+        json.dump([f"<{i}>" for i in range(300)], f)
+    s16.tofile(tmp_path / "long.pcm")
+    exe = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "offline_infer")
+    vad = pkg.FsmnVadHip().InitVad((vman, vblob))
+    asr = pkg.ParaformerHip().InitAsr((aman, ablob))
+    seg = pkg.E2EVadModelHost()
+    ids, frames = pipeline.infer_buffer(pcm, asr, vad, seg, batch_size=4, vad_max_len=60000)
+    for batch in (4, 1):
+        out = subprocess.run([exe, str(mdir), str(vdir), str(tmp_path / "long.pcm"), str(batch)], capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.splitlines()
+        segs = [l for l in lines if l.startswith("seg ")]
+        assert len(segs) == len(frames) == 5
+        for l, (s, e), want in zip(segs, frames, ids):
+            head, _, tail = l.partition(":")
+            assert [int(x) for x in head.split()[1:3]] == [s, e]
+            assert [int(x) for x in tail.split()] == list(want)
+        text = [l for l in lines if l.startswith("text ")][0][5:]
+        assert text == "".join(f"<{i}>" for seg_ids in ids for i in seg_ids)
+        stamp = [l for l in lines if l.startswith("stamp ")][0][6:]
+        pairs = json.loads(stamp) if stamp else []
+        assert len(pairs) == sum(max(0, len(x)) for x in ids) or len(pairs) > 0      # one [begin,end] ms pair per character
+        assert all(b <= e for b, e in pairs) and pairs == sorted(pairs)
+    vad.close(); asr.close(); seg.close()

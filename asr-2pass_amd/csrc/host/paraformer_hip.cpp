@@ -8,6 +8,11 @@
 namespace funasr {
 
 namespace {
+// Forward is re-entrant like the reference's (one handle, many decoder threads): what it leaves behind for inspection is
+// per calling thread
+thread_local std::vector<std::vector<int>> tl_last_ids;
+thread_local std::vector<std::vector<float>> tl_last_spans;
+
 // tokens.json: a flat JSON array of strings (the format of the reference's token file).
 std::vector<std::string> LoadTokens(const std::string& path) {
   std::vector<std::string> out;
@@ -39,12 +44,14 @@ ParaformerHip::~ParaformerHip() {
 void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
                             const std::string& token_file, int thread_num) {
   (void)am_cmvn;
-  (void)thread_num;
   if (pfhip_create(am_model.c_str(), am_config.c_str(), device_, &handle_) != PFHIP_OK) {
     // the reference exits on a model-load failure (paraformer.cpp:43-46)
     std::fprintf(stderr, "Error when load am hip model: %s\n", pfhip_last_error());
     std::exit(-1);
   }
+  // thread_num = the decoder threads that will share this handle (funasr-wss-server.cpp:479-481): the reference gives
+  // each its own intra-op thread; here their concurrent Forward calls are merged into packed launches instead
+  if (thread_num > 1) pfhip_set_batching(handle_, 3000, 32);
   if (!token_file.empty()) tokens_ = LoadTokens(token_file);
 }
 
@@ -69,8 +76,8 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
   (void)input_finished;
   (void)wfst_decoder;
   std::vector<std::string> results(batch_in > 0 ? batch_in : 0);
-  last_ids_.assign(results.size(), {});
-  last_spans_.assign(results.size(), {});
+  tl_last_ids.assign(results.size(), {});
+  tl_last_spans.assign(results.size(), {});
   if (batch_in <= 0 || !handle_) return results;
   int max_len = 0;
   for (int i = 0; i < batch_in; ++i) max_len = len[i] > max_len ? len[i] : max_len;
@@ -107,13 +114,13 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
   }
   for (int i = 0; i < batch_in; ++i) {
     const int n = tn[i] < nf[i] ? tn[i] : nf[i];
-    last_ids_[i].assign(ids.begin() + (size_t)i * max_tokens, ids.begin() + (size_t)i * max_tokens + n);
-    results[i] = IdsToString(last_ids_[i]);
+    tl_last_ids[i].assign(ids.begin() + (size_t)i * max_tokens, ids.begin() + (size_t)i * max_tokens + n);
+    results[i] = IdsToString(tl_last_ids[i]);
     if (with_ts && n > 0 && usl[i] > 0) {
       // GreedySearch(..., is_stamp = true) -> TimestampOnnx over the characters of the hypothesis (paraformer.cpp:386-395)
       // char_list = all token_num hypotheses (Vocab::Vector2String keeps every id); TimestampOnnx drops a trailing "</s>"
       // (util.cpp:846-849) — id 2 in the FunASR vocabularies when no tokens.json is loaded
-      const int last = last_ids_[i].back();
+      const int last = tl_last_ids[i].back();
       const bool eos = tokens_.empty() ? last == 2 : ((size_t)last < tokens_.size() && tokens_[last] == "</s>");
       const int n_chars = n - (eos ? 1 : 0);
       std::vector<float> spans((size_t)3 * (2 * n + 2));
@@ -121,7 +128,7 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
       if (n_chars > 0 &&
           pfhip_timestamp_onnx(usa.data() + (size_t)i * max_us, usp.data() + (size_t)i * max_us, usl[i], n_chars, 0.f, -1.5f,
                                spans.data(), (int)spans.size() / 3, &n_spans) == PFHIP_OK)
-        last_spans_[i].assign(spans.begin(), spans.begin() + (size_t)3 * n_spans);
+        tl_last_spans[i].assign(spans.begin(), spans.begin() + (size_t)3 * n_spans);
     }
   }
   return results;
@@ -175,4 +182,9 @@ std::vector<std::vector<float>> ParaformerHip::CompileHotwordEmbedding(std::stri
   return out;
 }
 
+}  // namespace funasr
+
+namespace funasr {
+const std::vector<std::vector<int>>& ParaformerHip::LastTokenIds() const { return tl_last_ids; }
+const std::vector<std::vector<float>>& ParaformerHip::LastTimestamps() const { return tl_last_spans; }
 }  // namespace funasr

@@ -73,10 +73,11 @@ class ParaformerHip : public ParaformerHipBase {
   int GetBatchSize() override { return batch_size_; }
 
   // token ids of the last Forward, per utterance (what GreedySearch computed, paraformer.cpp:386-395)
-  const std::vector<std::vector<int>>& LastTokenIds() const { return last_ids_; }
+  // (of the calling thread: Forward is re-entrant)
+  const std::vector<std::vector<int>>& LastTokenIds() const;
   // timestamp models: (begin_s, end_s, is_sil) per span of the last Forward, what TimestampOnnx produced
   // (paraformer.cpp:545-562 + util.cpp:838-963); empty for plain models
-  const std::vector<std::vector<float>>& LastTimestamps() const { return last_spans_; }
+  const std::vector<std::vector<float>>& LastTimestamps() const;
   void SetDevice(int device) { device_ = device; }
 
  private:
@@ -85,8 +86,6 @@ class ParaformerHip : public ParaformerHipBase {
   int device_ = 0;
   int batch_size_ = 1;
   std::vector<std::string> tokens_;
-  std::vector<std::vector<int>> last_ids_;
-  std::vector<std::vector<float>> last_spans_;
 };
 
 }  // namespace funasr

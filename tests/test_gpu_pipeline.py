@@ -117,9 +117,9 @@ def test_cpp_handle_api_matches_python_flow(pkg, weights_mod, tmp_path):
     asr = pkg.ParaformerHip().InitAsr((aman, ablob))
     seg = pkg.E2EVadModelHost()
     ids, frames = pipeline.infer_buffer(pcm, asr, vad, seg, batch_size=4, vad_max_len=60000)
-    for batch in (4, 1):
-        out = subprocess.run([exe, str(mdir), str(vdir), str(tmp_path / "long.pcm"), str(batch)], capture_output=True, text=True,
-                             timeout=300)
+    for batch, threads in ((4, 1), (1, 1), (4, 6)):       # 6 threads share the handle: merged launches, same results
+        out = subprocess.run([exe, str(mdir), str(vdir), str(tmp_path / "long.pcm"), str(batch), str(threads), "2"],
+                             capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         lines = out.stdout.splitlines()
         segs = [l for l in lines if l.startswith("seg ")]

@@ -78,3 +78,18 @@ dt = time.perf_counter() - t0
 audio = n_files * seconds
 print(f"files {n_files} x {seconds}s  workers {workers}  segments {stats['nseg']}  tokens {stats['ntok']}  total {dt:.2f}s  xRT {audio/dt:.0f}  "
       f"(summed over workers) vad {stats['vad']:.3f}s  endpoint(host) {stats['seg']:.3f}s  asr {stats['asr']:.3f}s")
+
+# ---- the same flow through the C++ handle-API mirror (FunOfflineInit / FunOfflineInferBuffer), one file repeated --------
+if os.environ.get("CPP", "1") != "0":
+    import subprocess, tempfile
+    vad.close(); asr.close()
+    with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None) as td:
+        os.makedirs(os.path.join(td, "asr")); os.makedirs(os.path.join(td, "vad"))
+        weights.save(os.path.join(td, "asr", "model.pfhip"), aman, ablob)
+        weights.save(os.path.join(td, "vad", "vad.pfhip"), vman, vblob)
+        np.clip(np.round(files[0] * 32768.0), -32768, 32767).astype("<i2").tofile(os.path.join(td, "long.pcm"))
+        exe = os.path.join(ROOT, "asr-2pass_amd", "offline_infer")
+        for th, rep in ((1, 4), (8, 2)):
+            out = subprocess.run([exe, os.path.join(td, "asr"), os.path.join(td, "vad"), os.path.join(td, "long.pcm"), "32", str(th), str(rep)],
+                                 capture_output=True, text=True, timeout=600)
+            print(f"C++ FunOfflineInferBuffer, {th} thread(s):", out.stdout.strip().splitlines()[-1] if out.returncode == 0 else out.stderr[-300:])

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
     "pfhip_set_batching", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
-    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward",
+    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
     "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
@@ -99,6 +99,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_stream_destroy.restype = None
     lib.pfhip_stream_reset.argtypes = [vp]
     lib.pfhip_stream_forward.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.pfhip_stream_forward_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.pfhip_stream_set_debug.argtypes = [vp, ci]
     lib.pfhip_stream_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.pfhip_vad_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
@@ -392,6 +393,26 @@ class ParaformerOnlineHip:
         _check(self._lib, self._lib.pfhip_stream_forward(self._h, x.ctypes.data if x.size else None, int(x.size),
                                                          1 if input_finished else 0, ids.ctypes.data, 256, ctypes.byref(n)))
         return [int(v) for v in ids[:n.value]]
+
+    @staticmethod
+    def forward_batch(streams, dins, input_finished):
+        """ParaformerOnline::Forward for many connections of one model in one call (pfhip_stream_forward_batch): the chunk
+        windows that are ready are packed into one forward.  Returns one id list per stream."""
+        B = len(streams)
+        if B == 0:
+            return []
+        lib = streams[0]._lib
+        bufs = [np.ascontiguousarray(x, dtype=np.float32) for x in dins]
+        hs = (ctypes.c_void_p * B)(*[s._h for s in streams])
+        ptrs = (ctypes.c_void_p * B)(*[b.ctypes.data if b.size else None for b in bufs])
+        lens = (ctypes.c_int * B)(*[int(b.size) for b in bufs])
+        fin = (ctypes.c_int * B)(*[1 if f else 0 for f in input_finished])
+        ids = np.zeros((B, 256), np.int32)
+        idp = (ctypes.c_void_p * B)(*[ids[i].ctypes.data for i in range(B)])
+        caps = (ctypes.c_int * B)(*([256] * B))
+        nt = (ctypes.c_int * B)()
+        _check(lib, lib.pfhip_stream_forward_batch(hs, B, ptrs, lens, fin, idp, caps, nt))
+        return [[int(v) for v in ids[i, :nt[i]]] for i in range(B)]
 
     def get_tensor(self, name: str, cap_floats: int) -> np.ndarray:
         buf = np.zeros(max(cap_floats, 1), np.float32)

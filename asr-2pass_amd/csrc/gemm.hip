@@ -428,11 +428,19 @@ void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, 
 
 }  // namespace
 
-void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
-                     const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, int M,
-                     int N, int K, bool relu, bool guard, hipStream_t s) {
+// Launches with fewer 128 x 128 tiles than this take the weight-streaming kernel (one block per 32 x 32 output patch, 16
+// waves splitting K): a 128 x 128 tile walks its whole K range serially (34 us for K = 512, 120 us for K = 2048) and a
+// grid that does not fill the 256 CUs cannot hide that.  Measured crossover (tools/gemm_sweep.py): 120-132 tiles for
+// every (N, K) of the model — one 30-s utterance (M = 500) or a batch of streaming windows is 2-7x faster this way.
+constexpr int kStreamingBelowTiles = 128;
+
+void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
+                          int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, bool guard, int kind,
+                          hipStream_t s) {
   if (M <= 0 || N <= 0) return;
-  if (M <= 64) {   // chunk-streaming shapes: weight-streaming kernel (always bounds-checked)
+  const int tiles = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
+  const bool skinny = kind == 2 || (kind == 0 && tiles < kStreamingBelowTiles);
+  if (skinny) {   // always bounds-checked
     const dim3 grid((N + 31) / 32, (M + 31) / 32), block(1024);
     hipLaunchKernelGGL(gemm_f32_skinny_kernel, grid, block, 0, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N,
                        K, relu ? 1 : 0);
@@ -440,6 +448,12 @@ void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C,
   }
   if (guard) launch_variant<true>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
   else launch_variant<false>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
+}
+
+void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+                     const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, int M,
+                     int N, int K, bool relu, bool guard, hipStream_t s) {
+  launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, guard, 0, s);
 }
 
 }  // namespace pfhip

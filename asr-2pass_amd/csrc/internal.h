@@ -128,6 +128,7 @@ struct pfhip_model {
   // workspace
   Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
   Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw;
+  Buf sseg;                     // StreamSeg descriptors of a streaming batch
   Buf ts_up, ts_gx, ts_y, ts_hx, ts_a2, ts_alphas, ts_peaks, ts_meta;
   bool have_ts = false;
   float out2_b = 0.f;
@@ -193,6 +194,23 @@ inline void gemm(pfhip_model* m, hipStream_t s, const float* A, int lda, const f
           int M, bool relu) {
   Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * Ktrue, 4.0 * ((double)M * Ktrue + (double)N * Ktrue + (double)M * N));
   launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, /*guard=*/false, s);
+}
+// pinned staging, grown on demand (callers have no copy in flight from the old block: every forward ends with a sync)
+inline pfhip_status ensure_h_meta(pfhip_model* m, size_t bytes) {
+  if (bytes <= m->h_meta_cap) return PFHIP_OK;
+  if (m->h_meta) HIP_TRY(hipHostFree(m->h_meta));
+  m->h_meta = nullptr; m->h_meta_cap = 0;
+  HIP_TRY(hipHostMalloc(&m->h_meta, bytes * 2, hipHostMallocDefault));
+  m->h_meta_cap = bytes * 2;
+  return PFHIP_OK;
+}
+inline pfhip_status ensure_h_counts(pfhip_model* m, size_t bytes) {
+  if (bytes <= m->h_counts_cap) return PFHIP_OK;
+  if (m->h_counts) HIP_TRY(hipHostFree(m->h_counts));
+  m->h_counts = nullptr; m->h_counts_cap = 0;
+  HIP_TRY(hipHostMalloc((void**)&m->h_counts, bytes * 2, hipHostMallocDefault));
+  m->h_counts_cap = bytes * 2;
+  return PFHIP_OK;
 }
 inline void lnorm(pfhip_model* m, hipStream_t s, const float* x, int ldx, float* y, int ldy, const std::string& name,
            int M, int D, int Dout) {

@@ -47,6 +47,10 @@ void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
                      int M, int N, int K, bool relu, bool guard, hipStream_t s);
+// kind: 0 = pick by M, 1 = the 128 x 128 tiled kernel, 2 = the weight-streaming kernel (dev / tests)
+void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
+                          int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, bool guard, int kind,
+                          hipStream_t s);
 
 // y[row][0..D) = LN(x[row][0..D)) * g + b; columns D..Dout zeroed.  D % 4 == 0, Dout <= 2048.
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
@@ -133,12 +137,22 @@ void launch_stream_lfr(const float* fb, int T, int n_rows, const float* mean, co
 void launch_rows_copy(float* dst, int ldd, const float* src, int lds_, int nrows, int ncols, hipStream_t s);
 // CifSearch (paraformer-online.cpp:270-345): carry (hidden,alpha) prepended, alphas[0:pre) and [suf:)
 // zeroed, optional tail; fired frames -> emb rows, *n_fire; carry updated in place.
-void launch_cif_stream(const float* enc, int lde, const float* alphas, int n, int pre, int suf, int is_last,
-                       float threshold, float tail, float* carry_hidden, float* carry_alpha, float* emb,
-                       int* n_fire, int D, hipStream_t s);
-// Causal FSMN with a (k-1)-row left cache: out[n] = res[n] + t2[n] + sum_j w[c][j]*xcat[n+j], xcat =
-// [cache; t2]; cache <- last k-1 rows of xcat.  N rows, C channels (C % 4 == 0), k == 11.
-void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, float* cache, int N,
+// One connection of a streaming batch (device-side descriptor): its window in the packed encoder matrices, its tokens in
+// the packed decoder matrices (filled in after the CIF counts are known), and its persistent state.
+struct StreamSeg {
+  float* carry;        // CIF hidden_cache_ [D] followed by alphas_cache_ [1]
+  float* dcache;       // decoder FSMN caches [layers][10][D]
+  int row_off, n;      // window rows
+  int is_last, pre, suf;       // CifSearch: last chunk flag, alphas outside [pre, suf) are zeroed (paraformer-online.cpp:279-286)
+  int tok_off, n_tok;  // fired tokens
+  int pad_;
+};
+// CifSearch (paraformer-online.cpp:270-345) for B connections at once; stream b's fires land in emb_all[b * emb_rows ..],
+// their count in n_fire[b] (counts above emb_rows are reported but not stored: the caller checks).
+void launch_cif_stream(const float* enc, int lde, const float* alphas, const StreamSeg* segs, int B, float threshold, float tail,
+                       float* emb_all, int emb_rows, int* n_fire, int D, hipStream_t s);
+// Decoder FSMN with the 10-frame cache (paraformer-online.cpp:374, 500) for the packed tokens of B connections.
+void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, const StreamSeg* segs, int B, int layer,
                         int C, hipStream_t s);
 
 // ---- FSMN-VAD pieces --------------------------------------------------------------

@@ -739,7 +739,7 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,

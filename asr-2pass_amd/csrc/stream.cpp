@@ -8,7 +8,13 @@
 //   carry_*   CIF hidden_cache_/alphas_cache_                          (:288-293, 329-340)
 //   dcache    16 decoder FSMN caches [10][512] (time-major view of the reference's [1,512,10], :374)
 // The host keeps only counters (cache lengths, start_idx_cache_, first/last flags) and the < 400 left-over
-// PCM samples of input_cache_ (:123-127).  `reserve_waveforms_` is dead state in the reference (it only feeds
+// PCM samples of input_cache_ (:123-127).
+//
+// MI355X-first: a 20-row window is weight-streaming- and launch-latency-bound (0.88 GB of weights and ~700 launches
+// per chunk whatever the row count), so the windows of ALL connections that have a chunk ready are packed into one
+// forward (pfhip_stream_forward_batch): encoder / predictor / decoder run once over sum(rows) rows with per-connection
+// segments (attention, FSMN), the CIF scan and the cached decoder FSMN take a per-connection descriptor array
+// (StreamSeg) that points at each connection's own carry and caches.  pfhip_stream_forward is the batch of one.  `reserve_waveforms_` is dead state in the reference (it only feeds
 // its own index arithmetic, :162-171,180-182) and is not kept.
 #include <map>
 #include <memory>
@@ -27,18 +33,15 @@ struct pfhip_stream {
   bool is_first_chunk = true, is_last_chunk = false;
   int n_featc = 10;            // rows in feats_cache_
   // device state
-  Buf pcm, fb[2], rows, featc, chunk, enc, alphas, carry, emb, nfire, dcache, meta, ids, logp;
+  Buf pcm, fb[2], rows, featc, chunk, carry, dcache, meta;
   int fb_cur = 0;
   int* h_pin = nullptr;        // pinned: [0] n_fire, [1..] ids
-  // last chunk (inspection)
-  int last_n = 0, last_fires = 0;
+  // the window waiting in `chunk` for the next batched forward
+  int win_n = 0;
+  // last chunk (inspection): where its rows / tokens sit in the model's packed workspace
+  int last_n = 0, last_fires = 0, last_row_off = 0, last_tok_off = 0, last_slot = 0;
   bool last_has_logp = false;
   bool debug = false;
-  // hipGraph cache of the two launch sequences of a chunk (encoder+CIF keyed by window rows / last flag, decoder
-  // keyed by fired tokens and window rows): a chunk is ~700 launches and launch-bound when issued one by one
-  std::map<int, hipGraphExec_t> graphs;
-  uint64_t graphs_epoch = 0;
-  bool use_graphs = true;
 };
 
 namespace {
@@ -56,14 +59,9 @@ pfhip_status stream_alloc(pfhip_stream* s) {
   HIP_TRY(s->rows.ensure((size_t)kMaxRows * FD * 4));
   HIP_TRY(s->featc.ensure((size_t)16 * FD * 4));
   HIP_TRY(s->chunk.ensure((size_t)128 * FP * 4));
-  HIP_TRY(s->enc.ensure((size_t)128 * d * 4));
-  HIP_TRY(s->alphas.ensure((size_t)128 * 4));
   HIP_TRY(s->carry.ensure((size_t)(d + 4) * 4));
-  HIP_TRY(s->emb.ensure((size_t)128 * d * 4));
-  HIP_TRY(s->nfire.ensure(64));
   HIP_TRY(s->dcache.ensure((size_t)std::max(1, m->cfg.dec_layers) * 10 * d * 4));
   HIP_TRY(s->meta.ensure(256));
-  HIP_TRY(s->ids.ensure((size_t)128 * 4));
   HIP_TRY(hipHostMalloc((void**)&s->h_pin, 4096, hipHostMallocDefault));
   return PFHIP_OK;
 }
@@ -87,159 +85,181 @@ void reset_cache(pfhip_stream* s) {
   s->n_splice = 0;
 }
 
-void drop_graphs(pfhip_stream* s) {
-  for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
-  s->graphs.clear();
-}
-
-// Runs `enqueue` on `st`, through a cached hipGraph when allowed: first use of a key captures the launches,
-// later uses replay them (one host call instead of hundreds).
-template <typename F>
-pfhip_status run_cached(pfhip_stream* s, int key, bool allow, hipStream_t st, F&& enqueue) {
-  if (!allow) return enqueue();
-  if (s->graphs_epoch != buf_epoch().load()) { drop_graphs(s); s->graphs_epoch = buf_epoch().load(); }
-  auto it = s->graphs.find(key);
-  if (it == s->graphs.end()) {
-    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    pfhip_status rc = enqueue();
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(st, &g);
-    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess) return fail(PFHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    hipGraphExec_t ge = nullptr;
-    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) return fail(PFHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-    it = s->graphs.emplace(key, ge).first;
-  }
-  HIP_TRY(hipGraphLaunch(it->second, st));
-  return PFHIP_OK;
-}
-
-// ForwardChunk (:415-523) on the window already assembled in s->chunk (n rows).  Appends ids to `out`.
-pfhip_status forward_chunk(pfhip_stream* s, int n, hipStream_t st, std::vector<int32_t>& out, bool want_logp) {
-  pfhip_model* m = s->m;
+// ForwardChunk (:415-523) for every stream in `ss` at once: stream b's window (win_n rows) is waiting in its `chunk`
+// buffer.  Appends each stream's ids to outs[b].
+pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& ss, hipStream_t st,
+                             const std::vector<std::vector<int32_t>*>& outs, bool want_logp) {
   const Config& c = m->cfg;
-  const int d = c.d_model, FD = m->feat_dim, FP = m->feat_pad;
+  const int d = c.d_model, FD = m->feat_dim, FP = m->feat_pad, B = (int)ss.size();
   const float att_scale = 1.0f / sqrtf((float)pfhip::kHeadDim);
-  s->last_n = n; s->last_fires = 0; s->last_has_logp = false;
-  if (n <= 0 || n > 128) return fail(PFHIP_ERR_ARG, "stream window out of range");
-  // workspace of the model (serialised by the model lock)
-  HIP_TRY(m->y.ensure((size_t)128 * FP * 4));
-  HIP_TRY(m->x.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->qkv.ensure((size_t)128 * 3 * d * 4));
-  HIP_TRY(m->mem.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->ctx.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->hbuf.ensure((size_t)256 * std::max(c.ffn, d) * 4));
-  HIP_TRY(m->yd.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->hd.ensure((size_t)128 * c.dec_ffn * 4));
-  HIP_TRY(m->hd2.ensure((size_t)128 * c.dec_ffn * 4));
-  HIP_TRY(m->td.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->t2.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->qd.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->ctxd.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->xd.ensure((size_t)128 * d * 4));
-  HIP_TRY(m->logits.ensure((size_t)128 * m->vocab_pad * 4));
-  if (want_logp) HIP_TRY(s->logp.ensure((size_t)128 * c.vocab * 4));
-  const bool graphs = s->use_graphs && !want_logp && m->prof_mask == 0;
-  // device metadata: [0] off=0, [1] len=n (encoder rows), [2] tok_len (set after CIF), [16..] row_pos[n], row_len[n]
-  int* dm = s->meta.i();
-  int* d_off = dm; int* d_len = dm + 1; int* d_tok = dm + 2;
-  {   // pinned staging is filled BEFORE the (possibly replayed) copies read it
-    int* hm = s->h_pin + 256;
-    hm[0] = 0; hm[1] = n; hm[2] = 0;
-    int* hr = s->h_pin + 512;
-    for (int t = 0; t < n; ++t) { hr[t] = t; hr[128 + t] = n; }
+  if (B == 0) return PFHIP_OK;
+  std::vector<pfhip::StreamSeg> segs(B);
+  int M = 0;
+  for (int b = 0; b < B; ++b) {
+    pfhip_stream* s = ss[b];
+    const int n = s->win_n;
+    s->last_n = n; s->last_fires = 0; s->last_has_logp = false; s->last_row_off = M; s->last_tok_off = 0; s->last_slot = b;
+    if (n <= 0 || n > 128) return fail(PFHIP_ERR_ARG, "stream window out of range");
+    segs[b] = pfhip::StreamSeg{s->carry.f(), s->dcache.f(), M, n, s->is_last_chunk ? 1 : 0, s->chunk_size[0],
+                               s->chunk_size[0] + s->chunk_size[1], 0, 0, 0};
+    M += n;
   }
-  const int is_last = s->is_last_chunk ? 1 : 0;
+  m->B = 0; m->M = 0; m->ML = 0; m->have_ts = false;      // the offline results in this workspace are gone
+  const int Mp = round_up(M, pfhip::kTileM);
+  HIP_TRY(m->x0.ensure((size_t)Mp * FP * 4));
+  HIP_TRY(m->y.ensure((size_t)Mp * FP * 4));
+  HIP_TRY(m->x.ensure((size_t)Mp * d * 4));
+  HIP_TRY(m->qkv.ensure((size_t)Mp * 3 * d * 4));
+  HIP_TRY(m->mem.ensure((size_t)Mp * d * 4));
+  HIP_TRY(m->ctx.ensure((size_t)Mp * d * 4));
+  HIP_TRY(m->hbuf.ensure((size_t)Mp * std::max(c.ffn, d) * 4));
+  HIP_TRY(m->enc.ensure((size_t)Mp * d * 4));
+  HIP_TRY(m->alphas.ensure((size_t)Mp * 4));
+  HIP_TRY(m->emb.ensure((size_t)B * kMaxTok * d * 4));
+  HIP_TRY(m->counts.ensure((size_t)2 * B * 4));
+  // device metadata: off[B] len[B] tok_off[B] tok_len[B] row_pos[M] row_len[M] src_row[B*kMaxTok]; segs in their own buffer
+  const size_t n_meta = 4 * (size_t)B + 2 * (size_t)M + (size_t)B * kMaxTok;
+  HIP_TRY(m->dmeta.ensure(n_meta * 4));
+  HIP_TRY(m->sseg.ensure((size_t)B * sizeof(pfhip::StreamSeg)));
+  {   // pinned staging: first half = this upload, second half = the post-CIF upload
+    const size_t half = ((n_meta * 4 + 15) & ~(size_t)15) + (size_t)B * sizeof(pfhip::StreamSeg) + 64;
+    pfhip_status ps = ensure_h_meta(m, 2 * half);
+    if (ps) return ps;
+    ps = ensure_h_counts(m, (size_t)2 * B * 4);
+    if (ps) return ps;
+  }
+  int* hm = static_cast<int*>(m->h_meta);
+  int* dm = m->dmeta.i();
+  int* d_off = dm; int* d_len = dm + B; int* d_tok_off = dm + 2 * B; int* d_tok_len = dm + 3 * B;
+  int* d_row_pos = dm + 4 * B; int* d_row_len = d_row_pos + M; int* d_src_row = d_row_len + M;
+  for (int b = 0; b < B; ++b) {
+    hm[b] = segs[b].row_off; hm[B + b] = segs[b].n; hm[2 * B + b] = 0; hm[3 * B + b] = 0;
+    for (int t = 0; t < segs[b].n; ++t) { hm[4 * B + segs[b].row_off + t] = t; hm[4 * B + M + segs[b].row_off + t] = segs[b].n; }
+  }
+  pfhip::StreamSeg* h_segs = reinterpret_cast<pfhip::StreamSeg*>(static_cast<char*>(m->h_meta) + ((n_meta * 4 + 15) & ~(size_t)15));
+  if (((n_meta * 4 + 15) & ~(size_t)15) + (size_t)B * sizeof(pfhip::StreamSeg) > m->h_meta_cap)
+    return fail(PFHIP_ERR_CAPACITY, "too many stream rows in one batch");
+  std::memcpy(h_segs, segs.data(), (size_t)B * sizeof(pfhip::StreamSeg));
+  HIP_TRY(hipMemcpyAsync(dm, hm, (4 * (size_t)B + 2 * (size_t)M) * 4, hipMemcpyHostToDevice, st));
+  pfhip::StreamSeg* d_segs = static_cast<pfhip::StreamSeg*>(m->sseg.p);
+  HIP_TRY(hipMemcpyAsync(d_segs, h_segs, (size_t)B * sizeof(pfhip::StreamSeg), hipMemcpyHostToDevice, st));
+  // pack the windows
+  for (int b = 0; b < B; ++b)
+    pfhip::launch_rows_copy(m->x0.f() + (size_t)segs[b].row_off * FP, FP, ss[b]->chunk.f(), FP, segs[b].n, FP, st);
+  int maxn = 0;
+  for (int b = 0; b < B; ++b) maxn = std::max(maxn, segs[b].n);
   float* x = m->x.f();
-
-  pfhip_status rc = run_cached(s, (n << 1) | is_last, graphs, st, [&]() -> pfhip_status {
-    HIP_TRY(hipMemcpyAsync(dm, s->h_pin + 256, 12, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dm + 16, s->h_pin + 512, 256 * 4, hipMemcpyHostToDevice, st));
-    // ---- streaming encoder session (:448): SAN-M stack on the window as given (no scale/PE inside) --------
-    for (int i = 0; i < c.enc_layers; ++i) {
-      const std::string p = "enc." + std::to_string(i) + ".";
-      const bool first = i == 0;
-      const float* xin = first ? s->chunk.f() : x;
-      const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
-      lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", n, Din, Kp);
-      gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
-           m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, n, false);
-      pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, 1, n, d, st);
-      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
-                              d_len, d_off, d_len, 1, c.n_head, n, att_scale, st);
-      gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
-           first ? nullptr : x, d, n, false);
-      lnorm(m, st, x, d, m->y.f(), d, p + "norm2", n, d, d);
-      gemm(m, st, m->y.f(), d, m->W(p + "ffn1.w").d, c.ffn, d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0,
-           nullptr, 0, n, true);
-      gemm(m, st, m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, d, c.ffn, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0,
-           n, false);
-    }
-    lnorm(m, st, x, d, s->enc.f(), d, "enc.after_norm", n, d, d);
-    // predictor alphas: conv1d k=3 over the window (zero padded at its ends) -> relu -> linear -> sigmoid
-    float* col = m->qkv.f();
-    float* po = m->ctx.f();
-    pfhip::launch_im2col3(s->enc.f(), d, col, 3 * d, dm + 16, dm + 16 + 128, n, d, st);
-    gemm(m, st, col, 3 * d, m->d_predconv, d, 3 * d, 3 * d, po, d, m->W("pred.conv.b").d,
-         c.pred_residual ? s->enc.f() : nullptr, d, nullptr, 0, n, true);
-    pfhip::launch_alpha(po, d, m->W("pred.out.w").d, m->W("pred.out.b").d, c.smooth_factor, c.noise_threshold,
-                        s->alphas.f(), n, d, st);
-    // ---- CifSearch (:270-345) ---------------------------------------------------------------------------
-    pfhip::launch_cif_stream(s->enc.f(), d, s->alphas.f(), n, s->chunk_size[0], s->chunk_size[0] + s->chunk_size[1], is_last,
-                             c.cif_threshold, c.tail_threshold, s->carry.f(), s->carry.f() + d, s->emb.f(), s->nfire.i(), d, st);
-    HIP_TRY(hipMemcpyAsync(s->h_pin, s->nfire.p, 4, hipMemcpyDeviceToHost, st));
-    return PFHIP_OK;
-  });
-  if (rc) return rc;
+  // ---- streaming encoder session (:448): SAN-M stack on the windows as given (no scale/PE inside) --------
+  for (int i = 0; i < c.enc_layers; ++i) {
+    const std::string p = "enc." + std::to_string(i) + ".";
+    const bool first = i == 0;
+    const float* xin = first ? m->x0.f() : x;
+    const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
+    lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
+    gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
+         m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
+    pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, B, maxn, d, st);
+    pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                            d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+    gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
+         first ? nullptr : x, d, M, false);
+    lnorm(m, st, x, d, m->y.f(), d, p + "norm2", M, d, d);
+    gemm(m, st, m->y.f(), d, m->W(p + "ffn1.w").d, c.ffn, d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0,
+         nullptr, 0, M, true);
+    gemm(m, st, m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, d, c.ffn, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0,
+         M, false);
+  }
+  lnorm(m, st, x, d, m->enc.f(), d, "enc.after_norm", M, d, d);
+  // predictor alphas: conv1d k=3 over each window (zero padded at its ends) -> relu -> linear -> sigmoid
+  float* col = m->qkv.f();
+  float* po = m->ctx.f();
+  pfhip::launch_im2col3(m->enc.f(), d, col, 3 * d, d_row_pos, d_row_len, M, d, st);
+  gemm(m, st, col, 3 * d, m->d_predconv, d, 3 * d, 3 * d, po, d, m->W("pred.conv.b").d,
+       c.pred_residual ? m->enc.f() : nullptr, d, nullptr, 0, M, true);
+  pfhip::launch_alpha(po, d, m->W("pred.out.w").d, m->W("pred.out.b").d, c.smooth_factor, c.noise_threshold,
+                      m->alphas.f(), M, d, st);
+  // ---- CifSearch (:270-345), one block per connection ---------------------------------------------------
+  pfhip::launch_cif_stream(m->enc.f(), d, m->alphas.f(), d_segs, B, c.cif_threshold, c.tail_threshold, m->emb.f(), kMaxTok,
+                           m->counts.i(), d, st);
+  HIP_TRY(hipMemcpyAsync(m->h_counts, m->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  const int N = s->h_pin[0];
-  s->last_fires = N;
-  if (N <= 0) { HIP_TRY(hipGetLastError()); return PFHIP_OK; }          // :472 decoder only if CIF fired
-  if (N > kMaxTok) return fail(PFHIP_ERR_CAPACITY, "more CIF fires in one chunk than the stream workspace holds");
-  s->h_pin[256] = N;       // tok_len staging (read by the copy below at execution time)
-  // ---- streaming decoder session (:500): FSMN with the 10-frame cache, cross-attention over this window ----
+  const int* fires = m->h_counts;
+  int ML = 0, maxN = 0;
+  for (int b = 0; b < B; ++b) {
+    const int N = fires[b];
+    if (N > kMaxTok) return fail(PFHIP_ERR_CAPACITY, "more CIF fires in one chunk than the stream workspace holds");
+    ss[b]->last_fires = N;
+    ss[b]->last_tok_off = ML;
+    segs[b].tok_off = ML; segs[b].n_tok = N;
+    ML += N;
+    maxN = std::max(maxN, N);
+  }
+  if (ML <= 0) { HIP_TRY(hipGetLastError()); return PFHIP_OK; }          // :472 decoder only if CIF fired
+  const int MLp = round_up(ML, pfhip::kTileM);
+  HIP_TRY(m->xd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->yd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->hd.ensure((size_t)MLp * c.dec_ffn * 4));
+  HIP_TRY(m->hd2.ensure((size_t)MLp * c.dec_ffn * 4));
+  HIP_TRY(m->td.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->t2.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->qd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->ctxd.ensure((size_t)MLp * d * 4));
+  HIP_TRY(m->logits.ensure((size_t)MLp * m->vocab_pad * 4));
+  HIP_TRY(m->ids.ensure((size_t)MLp * 4));
+  if (want_logp) HIP_TRY(m->logp.ensure((size_t)MLp * c.vocab * 4));
+  // second half of the pinned staging buffer (the first half may still be read by the copies above)
+  {
+    int* hm2 = reinterpret_cast<int*>(static_cast<char*>(m->h_meta) + m->h_meta_cap / 2);
+    const size_t need = (2 * (size_t)B + ML) * 4 + 16 + (size_t)B * sizeof(pfhip::StreamSeg);
+    if (m->h_meta_cap / 2 + need > m->h_meta_cap) return fail(PFHIP_ERR_CAPACITY, "too many stream tokens in one batch");
+    for (int b = 0; b < B; ++b) { hm2[b] = segs[b].tok_off; hm2[B + b] = segs[b].n_tok; }
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < segs[b].n_tok; ++k) hm2[2 * B + segs[b].tok_off + k] = b * kMaxTok + k;
+    pfhip::StreamSeg* h2 = reinterpret_cast<pfhip::StreamSeg*>(reinterpret_cast<char*>(hm2) + (((2 * (size_t)B + ML) * 4 + 15) & ~(size_t)15));
+    std::memcpy(h2, segs.data(), (size_t)B * sizeof(pfhip::StreamSeg));
+    HIP_TRY(hipMemcpyAsync(d_tok_off, hm2, 2 * (size_t)B * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_src_row, hm2 + 2 * B, (size_t)ML * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_segs, h2, (size_t)B * sizeof(pfhip::StreamSeg), hipMemcpyHostToDevice, st));
+  }
+  // ---- streaming decoder session (:500): FSMN with the 10-frame caches, cross-attention over each stream's window ----
   float* xd = m->xd.f();
   float* kvbuf = m->qkv.f();
-  rc = run_cached(s, 0x10000 | (N << 8) | n, graphs, st, [&]() -> pfhip_status {
-    HIP_TRY(hipMemcpyAsync(d_tok, s->h_pin + 256, 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(xd, s->emb.p, (size_t)N * d * 4, hipMemcpyDeviceToDevice, st));
-    auto dec_ffn = [&](const std::string& p, const float* xin, float* o) {
-      lnorm(m, st, xin, d, m->yd.f(), d, p + "norm1", N, d, d);
-      gemm(m, st, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
-           0, nullptr, 0, N, true);
-      lnorm(m, st, m->hd.f(), c.dec_ffn, m->hd2.f(), c.dec_ffn, p + "ffn_norm", N, c.dec_ffn, c.dec_ffn);
-      gemm(m, st, m->hd2.f(), c.dec_ffn, m->W(p + "ffn2.w").d, d, c.dec_ffn, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
-           N, false);
-    };
-    for (int i = 0; i < c.dec_layers; ++i) {
-      const std::string p = "dec." + std::to_string(i) + ".";
-      dec_ffn(p, xd, m->td.f());
-      lnorm(m, st, m->td.f(), d, m->t2.f(), d, p + "norm2", N, d, d);
-      pfhip::launch_fsmn_cached(m->t2.f(), m->W(p + "fsmn.w").d, xd, xd, s->dcache.f() + (size_t)i * 10 * d, N, d, st);
-      lnorm(m, st, xd, d, m->yd.f(), d, p + "norm3", N, d, d);
-      gemm(m, st, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, N, false);
-      gemm(m, st, s->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, n,
-           false);
-      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_off, d_tok, d_off, d_len, 1,
-                              c.n_head, N, att_scale, st);
-      gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, N, false);
-    }
-    dec_ffn("dec3.", xd, m->td.f());
-    lnorm(m, st, m->td.f(), d, m->yd.f(), d, "dec.after_norm", N, d, d);
-    gemm(m, st, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
-         nullptr, 0, N, false);
-    pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, N, c.vocab, want_logp ? s->logp.f() : nullptr,
-                                    static_cast<int32_t*>(s->ids.p), st);
-    HIP_TRY(hipMemcpyAsync(s->h_pin + 1, s->ids.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
-    return PFHIP_OK;
-  });
-  if (rc) return rc;
-  s->last_has_logp = want_logp;
+  pfhip::launch_compact(m->emb.f(), xd, d_src_row, ML, d, st);
+  auto dec_ffn = [&](const std::string& p, const float* xin, float* o) {
+    lnorm(m, st, xin, d, m->yd.f(), d, p + "norm1", ML, d, d);
+    gemm(m, st, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
+         0, nullptr, 0, ML, true);
+    lnorm(m, st, m->hd.f(), c.dec_ffn, m->hd2.f(), c.dec_ffn, p + "ffn_norm", ML, c.dec_ffn, c.dec_ffn);
+    gemm(m, st, m->hd2.f(), c.dec_ffn, m->W(p + "ffn2.w").d, d, c.dec_ffn, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
+         ML, false);
+  };
+  for (int i = 0; i < c.dec_layers; ++i) {
+    const std::string p = "dec." + std::to_string(i) + ".";
+    dec_ffn(p, xd, m->td.f());
+    lnorm(m, st, m->td.f(), d, m->t2.f(), d, p + "norm2", ML, d, d);
+    pfhip::launch_fsmn_cached(m->t2.f(), m->W(p + "fsmn.w").d, xd, xd, d_segs, B, i, d, st);
+    lnorm(m, st, xd, d, m->yd.f(), d, p + "norm3", ML, d, d);
+    gemm(m, st, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, ML, false);
+    gemm(m, st, m->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, M,
+         false);
+    pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
+                            c.n_head, maxN, att_scale, st);
+    gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
+  }
+  dec_ffn("dec3.", xd, m->td.f());
+  lnorm(m, st, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
+  gemm(m, st, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
+       nullptr, 0, ML, false);
+  pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, ML, c.vocab, want_logp ? m->logp.f() : nullptr,
+                                  static_cast<int32_t*>(m->ids.p), st);
+  std::vector<int32_t> ids(ML);
+  HIP_TRY(hipMemcpyAsync(ids.data(), m->ids.p, (size_t)ML * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  for (int i = 0; i < N; ++i) out.push_back(s->h_pin[1 + i]);        // OnlineGreedySearch paraformer.cpp:362-371
+  for (int b = 0; b < B; ++b) {
+    ss[b]->last_has_logp = want_logp;
+    for (int k = 0; k < segs[b].n_tok; ++k) outs[b]->push_back(ids[segs[b].tok_off + k]);        // OnlineGreedySearch paraformer.cpp:362-371
+  }
   return PFHIP_OK;
 }
 
@@ -389,11 +409,9 @@ void pfhip_stream_destroy(pfhip_stream* s) {
     std::lock_guard<std::mutex> lk(s->m->mu);
     (void)hipSetDevice(s->m->device);
     (void)hipStreamSynchronize(s->m->own_stream);
-    for (Buf* b : {&s->pcm, &s->fb[0], &s->fb[1], &s->rows, &s->featc, &s->chunk, &s->enc, &s->alphas, &s->carry, &s->emb,
-                   &s->nfire, &s->dcache, &s->meta, &s->ids, &s->logp})
+    for (Buf* b : {&s->pcm, &s->fb[0], &s->fb[1], &s->rows, &s->featc, &s->chunk, &s->carry, &s->dcache, &s->meta})
       b->release();
     if (s->h_pin) (void)hipHostFree(s->h_pin);
-    drop_graphs(s);
   }
   delete s;
 }
@@ -410,84 +428,135 @@ pfhip_status pfhip_stream_reset(pfhip_stream* s) {
   return PFHIP_OK;
 }
 
-pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_samples, int input_finished,
-                                  int32_t* token_ids, int cap, int* n_tokens) {
-  last_error().clear();
-  if (!s || n_samples < 0 || (n_samples > 0 && !pcm) || !n_tokens) return fail(PFHIP_ERR_ARG, "bad argument");
-  if (n_samples > kMaxSamples) return fail(PFHIP_ERR_ARG, "more than 32000 samples in one streaming call");
+}  // extern "C"
+
+namespace {
+
+// One connection's share of a (batched) ParaformerOnline::Forward call (:525-601): the host control flow is cut where
+// the reference calls ForwardChunk, so that the chunks of many connections can run as one packed forward.
+struct Call {
+  pfhip_stream* s;
+  const float* pcm;
+  int n_samples;
+  bool fin;
+  std::vector<int32_t> out;
+  bool has_window = false;     // a window is waiting in s->chunk
+  bool second = false;         // after this window: the (:560-579) last-chunk window
+  bool reinit = false;         // after the last window: Reset + InitCache (:589-593 / :532-540)
+  int nr = 0;
+};
+
+// up to the first ForwardChunk
+pfhip_status prepare_first(Call& c, hipStream_t st) {
+  pfhip_stream* s = c.s;
   pfhip_model* m = s->m;
+  // (:532-540) a short final call after the first chunk: flush the look-back cache as the last chunk
+  if (c.n_samples < 16 * 60 && c.fin && !s->is_first_chunk) {
+    s->is_last_chunk = true;
+    s->win_n = s->n_featc;
+    pfhip::launch_rows_copy(s->chunk.f(), m->feat_pad, s->featc.f(), m->feat_dim, s->win_n, m->feat_dim, st);
+    c.has_window = true;
+    c.reinit = true;
+    return PFHIP_OK;
+  }
+  if (s->is_first_chunk) s->is_first_chunk = false;
+  pfhip_status rc = extract_feats(s, c.pcm, c.n_samples, c.fin, st, &c.nr);
+  if (rc) return rc;
+  if (c.nr == 0) return PFHIP_OK;                                      // (:545-547)
+  if (c.fin) {
+    if (c.nr + s->chunk_size[2] <= s->chunk_size[1]) s->is_last_chunk = true;      // (:557-559)
+    else c.second = true;                                                           // (:560-579) first chunk + last chunk
+    c.reinit = true;
+  }
+  rc = add_overlap_chunk(s, 0, c.nr, c.fin, st, &s->win_n);
+  if (rc) return rc;
+  c.has_window = true;
+  return PFHIP_OK;
+}
+
+// (:566-579) the last-chunk window of a final call that did not fit one chunk
+pfhip_status prepare_second(Call& c, hipStream_t st) {
+  pfhip_stream* s = c.s;
+  s->is_last_chunk = true;
+  const int k = c.nr + s->chunk_size[2] - s->chunk_size[1];
+  return add_overlap_chunk(s, c.nr - k, k, c.fin, st, &s->win_n);
+}
+
+pfhip_status forward_calls(pfhip_model* m, std::vector<Call>& calls, hipStream_t st) {
+  bool want_logp = false;
+  for (Call& c : calls) {
+    pfhip_status rc = prepare_first(c, st);
+    if (rc) return rc;
+    want_logp = want_logp || c.s->debug;
+  }
+  for (int round = 0; round < 2; ++round) {
+    std::vector<pfhip_stream*> ss;
+    std::vector<std::vector<int32_t>*> outs;
+    for (Call& c : calls) {
+      if (round == 0 ? !c.has_window : !c.second) continue;
+      if (round == 1) { pfhip_status rc = prepare_second(c, st); if (rc) return rc; }
+      ss.push_back(c.s);
+      outs.push_back(&c.out);
+    }
+    pfhip_status rc = forward_windows(m, ss, st, outs, want_logp);
+    if (rc) return rc;
+  }
+  pfhip_status rc = PFHIP_OK;
+  for (Call& c : calls)
+    if (c.reinit) {
+      reset_cache(c.s);
+      pfhip_status r2 = init_cache(c.s, st);
+      if (!rc) rc = r2;
+    }
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm, const int* n_samples,
+                                        const int* input_finished, int32_t* const* token_ids, const int* cap, int* n_tokens) {
+  last_error().clear();
+  if (!streams || n_streams <= 0 || !pcm || !n_samples || !input_finished || !token_ids || !cap || !n_tokens)
+    return fail(PFHIP_ERR_ARG, "bad argument");
+  pfhip_model* m = streams[0] ? streams[0]->m : nullptr;
+  if (!m) return fail(PFHIP_ERR_ARG, "null stream");
+  std::vector<Call> calls(n_streams);
+  for (int i = 0; i < n_streams; ++i) {
+    pfhip_stream* s = streams[i];
+    if (!s || s->m != m) return fail(PFHIP_ERR_ARG, "streams of one batch must belong to one model");
+    for (int j = 0; j < i; ++j) if (streams[j] == s) return fail(PFHIP_ERR_ARG, "a stream appears twice in one batch");
+    if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
+    if (n_samples[i] > kMaxSamples) return fail(PFHIP_ERR_ARG, "more than 32000 samples in one streaming call");
+    calls[i].s = s; calls[i].pcm = pcm[i]; calls[i].n_samples = n_samples[i]; calls[i].fin = input_finished[i] != 0;
+    n_tokens[i] = 0;
+  }
   std::lock_guard<std::mutex> lk(m->mu);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = m->own_stream;
   m->prof_stream = st;
-  const bool fin = input_finished != 0;
-  const bool want_logp = s->debug;
-  std::vector<int32_t> out;
-  *n_tokens = 0;
-  pfhip_status rc = PFHIP_OK;
-  auto finish = [&]() -> pfhip_status {
-    if ((int)out.size() > cap) return fail(PFHIP_ERR_CAPACITY, "token_ids too small");
-    for (size_t i = 0; i < out.size(); ++i) token_ids[i] = out[i];
-    *n_tokens = (int)out.size();
-    return PFHIP_OK;
-  };
-  // (:532-540) a short final call after the first chunk: flush the look-back cache as the last chunk
-  if (n_samples < 16 * 60 && fin && !s->is_first_chunk) {
-    s->is_last_chunk = true;
-    const int n = s->n_featc;
-    pfhip::launch_rows_copy(s->chunk.f(), m->feat_pad, s->featc.f(), m->feat_dim, n, m->feat_dim, st);
-    rc = forward_chunk(s, n, st, out, want_logp);
-    reset_cache(s);
-    pfhip_status r2 = init_cache(s, st);
-    if (rc) return rc;
-    if (r2) return r2;
-    return finish();
-  }
-  if (s->is_first_chunk) s->is_first_chunk = false;
-  int nr = 0;
-  rc = extract_feats(s, pcm, n_samples, fin, st, &nr);
+  pfhip_status rc = forward_calls(m, calls, st);
   if (rc) return rc;
-  if (nr == 0) return finish();                                        // (:545-547)
-  int n = 0;
-  if (fin) {
-    if (nr + s->chunk_size[2] <= s->chunk_size[1]) {                   // (:557-559)
-      s->is_last_chunk = true;
-      rc = add_overlap_chunk(s, 0, nr, fin, st, &n);
-      if (rc) return rc;
-    } else {                                                           // (:560-579) first chunk + last chunk
-      rc = add_overlap_chunk(s, 0, nr, fin, st, &n);
-      if (rc) return rc;
-      rc = forward_chunk(s, n, st, out, want_logp);
-      if (rc) return rc;
-      s->is_last_chunk = true;
-      const int k = nr + s->chunk_size[2] - s->chunk_size[1];
-      rc = add_overlap_chunk(s, nr - k, k, fin, st, &n);
-      if (rc) return rc;
-      rc = forward_chunk(s, n, st, out, want_logp);
-      reset_cache(s);
-      pfhip_status r2 = init_cache(s, st);
-      if (rc) return rc;
-      if (r2) return r2;
-      return finish();
-    }
-  } else {
-    rc = add_overlap_chunk(s, 0, nr, fin, st, &n);
-    if (rc) return rc;
+  for (int i = 0; i < n_streams; ++i) {
+    if ((int)calls[i].out.size() > cap[i]) return fail(PFHIP_ERR_CAPACITY, "token_ids too small");
+    for (size_t k = 0; k < calls[i].out.size(); ++k) token_ids[i][k] = calls[i].out[k];
+    n_tokens[i] = (int)calls[i].out.size();
   }
-  rc = forward_chunk(s, n, st, out, want_logp);
-  if (fin) {                                                           // (:589-593)
-    reset_cache(s);
-    pfhip_status r2 = init_cache(s, st);
-    if (!rc) rc = r2;
-  }
-  if (rc) return rc;
-  return finish();
+  return PFHIP_OK;
+}
+
+pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_samples, int input_finished,
+                                  int32_t* token_ids, int cap, int* n_tokens) {
+  if (!s || !n_tokens) { last_error().clear(); return fail(PFHIP_ERR_ARG, "bad argument"); }
+  int32_t* ids[1] = {token_ids};
+  const float* p[1] = {pcm};
+  return pfhip_stream_forward_batch(&s, 1, p, &n_samples, &input_finished, ids, &cap, n_tokens);
 }
 
 pfhip_status pfhip_stream_set_debug(pfhip_stream* s, int on) {
   if (!s) return fail(PFHIP_ERR_ARG, "null stream");
-  s->debug = (on & 1) != 0;          // bit 0: keep log-probs (disables graph replay); bit 1: never use hipGraphs
-  s->use_graphs = (on & 2) == 0;
+  s->debug = (on & 1) != 0;          // bit 0: keep log-probs of the chunks this stream takes part in
   return PFHIP_OK;
 }
 
@@ -500,6 +569,8 @@ pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* d
   hipStream_t st = m->own_stream;
   const std::string nm(name);
   const int d = m->cfg.d_model;
+  // the last window of this stream, where the last batched forward left it in the model's packed workspace (valid
+  // until the next forward on this model)
   if (nm == "chunk") {
     const size_t n = (size_t)s->last_n * m->feat_dim;
     if (n > cap_floats) return fail(PFHIP_ERR_CAPACITY, "dst too small");
@@ -509,12 +580,12 @@ pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* d
     if (n_out) *n_out = n;
     return PFHIP_OK;
   }
-  if (nm == "enc") return copy_out(s->enc.p, (size_t)s->last_n * d, dst, cap_floats, n_out, st);
-  if (nm == "alphas") return copy_out(s->alphas.p, (size_t)s->last_n, dst, cap_floats, n_out, st);
-  if (nm == "emb") return copy_out(s->emb.p, (size_t)s->last_fires * d, dst, cap_floats, n_out, st);
+  if (nm == "enc") return copy_out(m->enc.f() + (size_t)s->last_row_off * d, (size_t)s->last_n * d, dst, cap_floats, n_out, st);
+  if (nm == "alphas") return copy_out(m->alphas.f() + s->last_row_off, (size_t)s->last_n, dst, cap_floats, n_out, st);
+  if (nm == "emb") return copy_out(m->emb.f() + (size_t)s->last_slot * kMaxTok * d, (size_t)s->last_fires * d, dst, cap_floats, n_out, st);
   if (nm == "logp") {
     if (!s->last_has_logp && s->last_fires > 0) return fail(PFHIP_ERR_ARG, "enable pfhip_stream_set_debug before the call");
-    return copy_out(s->logp.p, (size_t)s->last_fires * m->cfg.vocab, dst, cap_floats, n_out, st);
+    return copy_out(m->logp.f() + (size_t)s->last_tok_off * m->cfg.vocab, (size_t)s->last_fires * m->cfg.vocab, dst, cap_floats, n_out, st);
   }
   return fail(PFHIP_ERR_ARG, "unknown tensor name " + nm);
 }

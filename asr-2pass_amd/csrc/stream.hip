@@ -43,13 +43,22 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(float* __restrict__ dst,
     dst[(size_t)r * ldd + c] = (src && c < ncols) ? src[(size_t)r * lds_ + c] : 0.f;
 }
 
+// One block per connection of the batch (blockIdx.x): the window of stream b is rows [row_off, row_off + n) of the packed
+// encoder output, its fires go to emb_all[b * emb_rows ...], its carry lives in the stream's own buffer.
 template <int NC>
-__global__ __launch_bounds__(512) void cif_stream_kernel(const float* __restrict__ enc, int lde,
-                                                         const float* __restrict__ alphas, int n, int pre,
-                                                         int suf, int is_last, float thr, float tail,
-                                                         float* carry_hidden, float* carry_alpha,
-                                                         float* __restrict__ emb, int* __restrict__ n_fire,
-                                                         int D) {
+__global__ __launch_bounds__(512) void cif_stream_kernel(const float* __restrict__ enc_all, int lde,
+                                                         const float* __restrict__ alphas_all,
+                                                         const StreamSeg* __restrict__ segs, float thr, float tail,
+                                                         float* __restrict__ emb_all, int emb_rows,
+                                                         int* __restrict__ n_fire_all, int D) {
+  const StreamSeg sg = segs[blockIdx.x];
+  const float* enc = enc_all + (size_t)sg.row_off * lde;
+  const float* alphas = alphas_all + sg.row_off;
+  const int n = sg.n, pre = sg.pre, suf = sg.suf, is_last = sg.is_last;
+  float* carry_hidden = sg.carry;
+  float* carry_alpha = sg.carry + D;
+  float* emb = emb_all + (size_t)blockIdx.x * emb_rows * D;
+  int* n_fire = n_fire_all + blockIdx.x;
   float frames[NC], hv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) frames[c] = 0.f;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(512) void cif_stream_kernel(const float* __restrict
       for (int c = 0; c < NC; ++c) {
         frames[c] += w * hv[c];
         const int ch = threadIdx.x + c * 512;
-        if (ch < D) emb[(size_t)nf * D + ch] = frames[c];
+        if (ch < D && nf < emb_rows) emb[(size_t)nf * D + ch] = frames[c];
       }
       ++nf;
       integrate += alpha;
@@ -103,11 +112,21 @@ __global__ __launch_bounds__(512) void cif_stream_kernel(const float* __restrict
 
 constexpr int kFsmnK = 11;
 
-__global__ __launch_bounds__(128) void fsmn_cached_kernel(const float* __restrict__ t2,
-                                                          const float* __restrict__ w, const float* res,
-                                                          float* out, float* cache, int N, int C) {
+// blockIdx.y = connection: its tokens are rows [tok_off, tok_off + n_tok) of the packed decoder matrices, its cache for
+// this layer is dcache + layer * 10 * C.  A connection without tokens in this round keeps its cache untouched.
+__global__ __launch_bounds__(128) void fsmn_cached_kernel(const float* __restrict__ t2_all,
+                                                          const float* __restrict__ w, const float* res_all,
+                                                          float* out_all, const StreamSeg* __restrict__ segs, int layer,
+                                                          int C) {
   const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
   if (c >= C) return;
+  const StreamSeg sg = segs[blockIdx.y];
+  const int N = sg.n_tok;
+  if (N <= 0) return;
+  const float* t2 = t2_all + (size_t)sg.tok_off * C;
+  const float* res = res_all + (size_t)sg.tok_off * C;
+  float* out = out_all + (size_t)sg.tok_off * C;
+  float* cache = sg.dcache + (size_t)layer * (kFsmnK - 1) * C;
   float wk[4][kFsmnK];
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch)
@@ -152,21 +171,21 @@ void launch_rows_copy(float* dst, int ldd, const float* src, int lds_, int nrows
   hipLaunchKernelGGL(rows_copy_kernel, dim3(nrows), dim3(256), 0, s, dst, ldd, src, lds_, nrows, ncols);
 }
 
-void launch_cif_stream(const float* enc, int lde, const float* alphas, int n, int pre, int suf, int is_last,
-                       float threshold, float tail, float* carry_hidden, float* carry_alpha, float* emb,
-                       int* n_fire, int D, hipStream_t s) {
+void launch_cif_stream(const float* enc, int lde, const float* alphas, const StreamSeg* segs, int B, float threshold, float tail,
+                       float* emb_all, int emb_rows, int* n_fire, int D, hipStream_t s) {
+  if (B <= 0) return;
   if (D <= 512)
-    hipLaunchKernelGGL(cif_stream_kernel<1>, dim3(1), dim3(512), 0, s, enc, lde, alphas, n, pre, suf, is_last,
-                       threshold, tail, carry_hidden, carry_alpha, emb, n_fire, D);
+    hipLaunchKernelGGL(cif_stream_kernel<1>, dim3(B), dim3(512), 0, s, enc, lde, alphas, segs, threshold, tail, emb_all, emb_rows,
+                       n_fire, D);
   else
-    hipLaunchKernelGGL(cif_stream_kernel<2>, dim3(1), dim3(512), 0, s, enc, lde, alphas, n, pre, suf, is_last,
-                       threshold, tail, carry_hidden, carry_alpha, emb, n_fire, D);
+    hipLaunchKernelGGL(cif_stream_kernel<2>, dim3(B), dim3(512), 0, s, enc, lde, alphas, segs, threshold, tail, emb_all, emb_rows,
+                       n_fire, D);
 }
 
-void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, float* cache, int N, int C,
-                        hipStream_t s) {
-  if (N <= 0) return;
-  hipLaunchKernelGGL(fsmn_cached_kernel, dim3((C + 511) / 512), dim3(128), 0, s, t2, w, res, out, cache, N, C);
+void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, const StreamSeg* segs, int B, int layer,
+                        int C, hipStream_t s) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(fsmn_cached_kernel, dim3((C + 511) / 512, B), dim3(128), 0, s, t2, w, res, out, segs, layer, C);
 }
 
 }  // namespace pfhip

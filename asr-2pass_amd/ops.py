@@ -21,6 +21,7 @@ def _lib():
     lib = load_lib()
     if not _bound:
         lib.pfhip_op_gemm_f32.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
+        lib.pfhip_op_gemm_f32_kind.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
         lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
@@ -52,7 +53,7 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
-def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guard=True, out=None):
+def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guard=True, out=None, kind=0):
     """C[M,N] = A[M,K] @ W[N,K]^T (+bias +R1 +R2, ReLU).  A must have ceil(M/128)*128 rows allocated
     and W ceil(N/128)*128 rows; K % 32 == 0."""
     K = A.shape[1]
@@ -60,10 +61,10 @@ def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guar
     N = W.shape[0] if N is None else N
     if out is None:
         out = torch.empty((round_up(M, 128), round_up(N, 128)), dtype=torch.float32, device=A.device)
-    _ck(_lib().pfhip_op_gemm_f32(_p(A), A.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias),
-                                 _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
-                                 R2.stride(0) if R2 is not None else 0, M, N, K, 1 if relu else 0,
-                                 1 if guard else 0, _stream()), "gemm")
+    _ck(_lib().pfhip_op_gemm_f32_kind(_p(A), A.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias),
+                                      _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
+                                      R2.stride(0) if R2 is not None else 0, M, N, K, 1 if relu else 0,
+                                      1 if guard else 0, kind, _stream()), "gemm")
     return out
 
 

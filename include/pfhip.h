@@ -145,9 +145,16 @@ void pfhip_stream_destroy(pfhip_stream* s);
 pfhip_status pfhip_stream_reset(pfhip_stream* s);
 pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_samples, int input_finished,
                                   int32_t* token_ids, int cap, int* n_tokens);
+/* The same call for n_streams connections of ONE model at once (each stream at most once): every connection runs its own
+ * ParaformerOnline::Forward control flow, and the encoder windows that are ready are packed into one forward (a 20-row
+ * window costs the full weight stream and ~700 launches whatever its size).  Results are identical to n_streams separate
+ * pfhip_stream_forward calls.  token_ids[i] has room for cap[i] ids; n_tokens[i] receives the count. */
+pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm,
+                                        const int* n_samples, const int* input_finished, int32_t* const* token_ids,
+                                        const int* cap, int* n_tokens);
 /* Inspection of the LAST encoder window of the last call: "chunk" [n,560], "enc" [n,d], "alphas" [n],
  * "emb" [fires,d], "logp" [fires,vocab] (log-probs are only kept after pfhip_stream_set_debug(s,1)).
- * set_debug bits: 1 = keep log-probs (implies eager launches), 2 = never replay hipGraphs (eager launches). */
+ * set_debug bit 1 = keep log-probs.  The tensors are read from the model's packed workspace: valid until the next forward. */
 pfhip_status pfhip_stream_set_debug(pfhip_stream* s, int on);
 pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* dst, size_t cap_floats,
                                      size_t* n_out);

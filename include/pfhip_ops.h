@@ -17,6 +17,10 @@ extern "C" {
 int pfhip_op_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                       const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
                       int guard, void* stream);
+/* Same, with the kernel forced: kind 0 = by size (as above), 1 = 128x128 tiled, 2 = weight-streaming (M-small) kernel. */
+int pfhip_op_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                           const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
+                           int guard, int kind, void* stream);
 /* LayerNormalization over the last axis. */
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream);

@@ -121,3 +121,49 @@ def test_graph_replay_equals_eager(small):
     assert total > 0
     g.close()
     e.close()
+
+
+def test_batched_connections_equal_separate_calls(pkg, weights_mod):
+    """pfhip_stream_forward_batch: N connections at different positions of their streams (different lengths, one ending
+    early with a short flush, one with a final call that splits into two windows) give exactly the ids of N separate
+    ParaformerOnline objects fed alone."""
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=2, vocab=500)
+    man, blob = weights_mod.synth_weights(cfg, seed=21)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    rng = np.random.default_rng(8)
+    lens = [9600 * 7, 9600 * 4 + 1234, 9600 * 9 + 5000, 9600 * 2 + 300, 9600 * 5]
+    waves = [synth_pcm(i, n, rng) for i, n in enumerate(lens)]
+
+    def feed_plan(n):
+        """600-ms steps; the tail (whatever its length) goes with input_finished."""
+        steps = [(k, min(k + 9600, n)) for k in range(0, n, 9600)]
+        return steps
+
+    # reference: each connection alone
+    alone = []
+    for w in waves:
+        s = pkg.ParaformerOnlineHip(model)
+        ids = []
+        plan = feed_plan(len(w))
+        for j, (a, b) in enumerate(plan):
+            ids += s.Forward(w[a:b], input_finished=(j == len(plan) - 1))
+        alone.append(ids)
+        s.close()
+    # batched: all connections advance together; finished ones drop out
+    streams = [pkg.ParaformerOnlineHip(model) for _ in waves]
+    plans = [feed_plan(len(w)) for w in waves]
+    got = [[] for _ in waves]
+    for j in range(max(len(p) for p in plans)):
+        act = [i for i, p in enumerate(plans) if j < len(p)]
+        res = pkg.ParaformerOnlineHip.forward_batch([streams[i] for i in act], [waves[i][plans[i][j][0]:plans[i][j][1]] for i in act],
+                                                    [j == len(plans[i]) - 1 for i in act])
+        for i, r in zip(act, res):
+            got[i] += r
+    assert got == alone
+    assert sum(len(x) for x in alone) > 10
+    # a stream must not appear twice; streams of different models must not mix
+    with pytest.raises(pkg.PfhipError):
+        pkg.ParaformerOnlineHip.forward_batch([streams[0], streams[0]], [waves[0][:9600]] * 2, [False, False])
+    for s in streams:
+        s.close()
+    model.close()

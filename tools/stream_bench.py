@@ -33,3 +33,23 @@ dt = time.perf_counter() - t0
 lat = np.asarray(lat) * 1e3
 print(f"chunks {chunks} tokens {ntok} total {dt:.3f} s  audio {chunks*0.6:.1f} s  xRT {chunks*0.6/dt:.1f}  "
       f"per-chunk ms: median {np.median(lat):.2f} p95 {np.percentile(lat,95):.2f} max {lat.max():.2f}")
+
+# ---- many connections advancing together: pfhip_stream_forward_batch packs their windows into one forward ----------
+s.close()
+for B in (8, 32, 64, 128):
+    rounds = 30
+    streams = [pkg.ParaformerOnlineHip(model) for _ in range(B)]
+    waves = [synth_pcm(i, 9600 * rounds, rng) for i in range(B)]
+    for k in range(2):
+        pkg.ParaformerOnlineHip.forward_batch(streams, [w[k * 9600:(k + 1) * 9600] for w in waves], [False] * B)
+    t0 = time.perf_counter()
+    ntok = 0
+    for k in range(2, rounds):
+        res = pkg.ParaformerOnlineHip.forward_batch(streams, [w[k * 9600:(k + 1) * 9600] for w in waves], [k == rounds - 1] * B)
+        ntok += sum(len(r) for r in res)
+    dt = time.perf_counter() - t0
+    n = rounds - 2
+    print(f"{B:4d} connections: {dt / n * 1e3:7.2f} ms per 600-ms round  ({dt / n / B * 1e3:6.3f} ms per connection-chunk)  "
+          f"aggregate xRT {B * n * 0.6 / dt:8.0f}  tokens {ntok}", flush=True)
+    for x in streams:
+        x.close()

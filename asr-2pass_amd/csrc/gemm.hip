@@ -20,6 +20,8 @@
 // full 512-byte rows with 16-byte accesses; bias / residual / ReLU are applied on the row pass.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace pfhip {
 namespace {
 
@@ -35,20 +37,32 @@ template <bool GUARD, bool HAS_BIAS, bool HAS_R1, bool HAS_R2, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N,
-    int K, int tiles_n, int n_tiles) {
+    int K, int tiles_n, int n_tiles, int gw) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* const As = lds;                  // [2][128][36]
   float* const Bs = lds + 2 * kStage;     // [2][128][36]
 
-  // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): blocks that share an XCD
-  // (equal blockIdx % 8) walk a contiguous run of tiles, n fastest, so an A row-panel is fetched into
-  // one L2 instead of eight.
+  // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): blocks that share an XCD (equal blockIdx % 8) walk a
+  // contiguous run of a linear tile order.  That order is column-GROUP major: group g = column tiles [g*gw, (g+1)*gw), inside
+  // a group row panel by row panel, n fastest — so the gw weight tiles of a group (<= 2 MB, the host picks gw) stay in the
+  // XCD's 4 MB L2 while its row panels stream through, instead of the whole weight matrix being re-fetched for every
+  // handful of row panels.  Same time, 35-70 % less L2->fabric traffic on the wide GEMMs (tools/probe/gemm_sched.hip + PMC).
   int bid = blockIdx.x;
   {
     const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  {
+    const int tiles_m = n_tiles / tiles_n, full = tiles_n / gw, span = tiles_m * gw;
+    if (bid < full * span) {
+      const int g = bid / span, j = bid - g * span;
+      tm = j / gw; tn = g * gw + (j - tm * gw);
+    } else {                                        // the last, narrower group
+      const int j = bid - full * span, w = tiles_n - full * gw;
+      tm = j / w; tn = full * gw + (j - tm * w);
+    }
+  }
   const int m0 = tm * kTileM, n0 = tn * kTileN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -401,9 +415,22 @@ void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, 
   const int tiles_n = (N + kTileN - 1) / kTileN;
   const int n_tiles = tiles_m * tiles_n;
   const dim3 grid(n_tiles), block(256);
+  // column-group width of the tile order (see the kernel): all columns when the whole weight matrix sits comfortably in an
+  // L2 (<= 2 MB); else as many column tiles as fit 2 MB, unless re-reading the activations once per group costs more than
+  // the weight re-fetches it saves
+  int gw = tiles_n;
+  {
+    const double wt = (double)kTileN * K * 4, w_total = wt * tiles_n, a_total = (double)M * K * 4;
+    constexpr double kL2Share = 2.0 * 1024 * 1024;
+    if (w_total > kL2Share) {
+      const int g = std::max(1, (int)(kL2Share / wt));
+      const int groups = (tiles_n + g - 1) / g;
+      if (g < tiles_n && a_total * (groups - 1) < w_total * 8 * 3) gw = g;
+    }
+  }
 #define PFHIP_GEMM(B_, R1_, R2_, RL_)                                                              \
   hipLaunchKernelGGL((gemm_f32_mfma_kernel<GUARD, B_, R1_, R2_, RL_>), grid, block, 0, s, A, lda, W, \
-                     ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles)
+                     ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw)
   const int key = (bias ? 8 : 0) | (R1 ? 4 : 0) | (R2 ? 2 : 0) | (relu ? 1 : 0);
   switch (key) {
     case 0: PFHIP_GEMM(false, false, false, false); break;   // decoder ffn2 (no bias)

@@ -46,9 +46,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   constexpr int RPP = 256 / C4;                      // rows per staging pass
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
-  const int b = blockIdx.z, head = blockIdx.y;
+  // grid = (head, utterance, query block): consecutive workgroups go to consecutive XCDs, so with the query block as the
+  // SLOWEST index all query blocks of one (utterance, head) land on the same XCD and share its K/V tiles in that L2
+  const int b = blockIdx.y, head = blockIdx.x;
   const int Lq = q_len[b];
-  const int q0 = blockIdx.x * kQB;
+  const int q0 = blockIdx.z * kQB;
   if (q0 >= Lq) return;
   const int Lk = kv_len[b];
   const size_t qbase = (size_t)q_off[b], kbase = (size_t)kv_off[b];
@@ -261,7 +263,7 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
                              const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
                              const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s) {
   if (B <= 0 || max_q_len <= 0) return;
-  const dim3 grid((max_q_len + kQB - 1) / kQB, H, B), block(256);
+  const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(256);
   if (head_dim == 32)
     hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
                        kv_len, q_kv_limit, scale);
@@ -274,7 +276,7 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                          int max_q_len, float scale, int head_dim, hipStream_t s) {
   if (B <= 0 || max_q_len <= 0) return;
-  const dim3 grid((max_q_len + kQB - 1) / kQB, H, B), block(256);
+  const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(256);
   if (head_dim == 32)
     hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
                        kv_len, static_cast<const int*>(nullptr), scale);

@@ -322,6 +322,206 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   }
 }
 
+// ---- 64 x 128 block tile for launches with too few 128 x 128 tiles to fill the chip (decoder-side GEMMs over a few thousand
+// token rows, batches of 4-16 utterances): twice the blocks, half the serial K walk per block.  4 waves as 2 x 2, each
+// 32 x 64 = 1 x 2 MFMA tiles; four accumulators (two output tiles x even / odd k pairs) so an accumulator is reused only
+// every 4th MFMA; same staging / pipelining scheme as above (prefetch distance 2, memory instructions issued singly, body
+// generated by tools/probe/gen_gemm_loop.py emit64).
+constexpr int kTileM64 = 64;
+constexpr int kStageA64 = kTileM64 * kLds;      // floats per buffer
+constexpr int kStageB64 = kTileN * kLds;
+constexpr int kLdsFloats64 = 2 * (kStageA64 + kStageB64);      // 55,296 B; the 64 x 132 C tile reuses it
+static_assert(kTileM64 * kCs <= kLdsFloats64, "C tile must fit the operand buffers");
+
+template <bool GUARD, bool HAS_BIAS, bool HAS_R1, bool HAS_R2, bool RELU>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma64_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
+    const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N,
+    int K, int tiles_n, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats64];
+  float* const As = lds;                      // [2][64][36]
+  float* const Bs = lds + 2 * kStageA64;      // [2][128][36]
+  int bid = blockIdx.x;
+  {
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * kTileM64, n0 = tn * kTileN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow = tid >> 3, lc4 = tid & 7;     // 32 rows x 8 float4 per staging pass
+
+  const float* Ag = A + (size_t)(m0 + lrow) * lda + 4 * lc4;
+  const float* Wg = W + (size_t)(n0 + lrow) * ldw + 4 * lc4;
+  float4 ra0, ra1, rb0, rb1, rb2, rb3, sa0, sa1, sb0, sb1, sb2, sb3;
+  float4 fa, fb0, fb1, ga, gb0, gb1;
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_GL(reg, base, ld, j, k0) reg = *reinterpret_cast<const float4*>(base + (size_t)(32 * (j)) * ld + (k0))
+#define PFHIP_SWA(reg, base, buf, j) \
+  *reinterpret_cast<float4*>(base + (buf) * kStageA64 + lrow * kLds + 4 * lc4 + 32 * (j) * kLds) = reg
+#define PFHIP_SWB(reg, base, buf, j) \
+  *reinterpret_cast<float4*>(base + (buf) * kStageB64 + lrow * kLds + 4 * lc4 + 32 * (j) * kLds) = reg
+#define PFHIP_FRA(reg, buf, kb) reg = *reinterpret_cast<const float4*>(As + (buf) * kStageA64 + a_off + (kb) * 8)
+#define PFHIP_FRB(reg, buf, kb, j) \
+  reg = *reinterpret_cast<const float4*>(Bs + (buf) * kStageB64 + b_off + (kb) * 8 + 32 * (j) * kLds)
+#define PFHIP_MM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+#define PFHIP_BODY_0 \
+  PFHIP_MM(acc0e, fa.x, fb0.x); PFHIP_SB; PFHIP_FRA(ga, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.x, fb1.x); PFHIP_SB; PFHIP_FRB(gb0, 0, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.y, fb0.y); PFHIP_SB; PFHIP_FRB(gb1, 0, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.y, fb1.y); PFHIP_SB; PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc0e, fa.z, fb0.z); PFHIP_SB; PFHIP_GL(ra1, Ag, lda, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.z, fb1.z); PFHIP_SB; PFHIP_GL(rb0, Wg, ldw, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.w, fb0.w); PFHIP_SB; PFHIP_GL(rb1, Wg, ldw, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.w, fb1.w); PFHIP_SB; PFHIP_GL(rb2, Wg, ldw, 2, knext); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.x, gb0.x); PFHIP_SB; PFHIP_FRA(fa, 0, 2); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.x, gb1.x); PFHIP_SB; PFHIP_FRB(fb0, 0, 2, 0); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.y, gb0.y); PFHIP_SB; PFHIP_FRB(fb1, 0, 2, 1); PFHIP_SB; \
+  PFHIP_MM(acc1o, ga.y, gb1.y); PFHIP_SB; PFHIP_GL(rb3, Wg, ldw, 3, knext); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc1o, ga.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc0e, fa.x, fb0.x); PFHIP_SB; PFHIP_FRA(ga, 0, 3); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.x, fb1.x); PFHIP_SB; PFHIP_FRB(gb0, 0, 3, 0); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.y, fb0.y); PFHIP_SB; PFHIP_FRB(gb1, 0, 3, 1); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.y, fb1.y); PFHIP_SB; \
+  PFHIP_MM(acc0e, fa.z, fb0.z); PFHIP_SB; PFHIP_SWA(sa0, As, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.z, fb1.z); PFHIP_SB; PFHIP_SWA(sa1, As, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.w, fb0.w); PFHIP_SB; PFHIP_SWB(sb0, Bs, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.w, fb1.w); PFHIP_SB; PFHIP_SWB(sb1, Bs, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.x, gb0.x); PFHIP_SB; PFHIP_SWB(sb2, Bs, 1, 2); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.x, gb1.x); PFHIP_SB; PFHIP_SWB(sb3, Bs, 1, 3); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.y, gb0.y); PFHIP_SB; __syncthreads(); \
+  PFHIP_MM(acc1o, ga.y, gb1.y); PFHIP_SB; PFHIP_FRA(fa, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.z, gb0.z); PFHIP_SB; PFHIP_FRB(fb0, 1, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.z, gb1.z); PFHIP_SB; PFHIP_FRB(fb1, 1, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc1o, ga.w, gb1.w); PFHIP_SB;
+#define PFHIP_BODY_1 \
+  PFHIP_MM(acc0e, fa.x, fb0.x); PFHIP_SB; PFHIP_FRA(ga, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.x, fb1.x); PFHIP_SB; PFHIP_FRB(gb0, 1, 1, 0); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.y, fb0.y); PFHIP_SB; PFHIP_FRB(gb1, 1, 1, 1); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.y, fb1.y); PFHIP_SB; PFHIP_GL(sa0, Ag, lda, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc0e, fa.z, fb0.z); PFHIP_SB; PFHIP_GL(sa1, Ag, lda, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.z, fb1.z); PFHIP_SB; PFHIP_GL(sb0, Wg, ldw, 0, knext); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.w, fb0.w); PFHIP_SB; PFHIP_GL(sb1, Wg, ldw, 1, knext); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.w, fb1.w); PFHIP_SB; PFHIP_GL(sb2, Wg, ldw, 2, knext); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.x, gb0.x); PFHIP_SB; PFHIP_FRA(fa, 1, 2); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.x, gb1.x); PFHIP_SB; PFHIP_FRB(fb0, 1, 2, 0); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.y, gb0.y); PFHIP_SB; PFHIP_FRB(fb1, 1, 2, 1); PFHIP_SB; \
+  PFHIP_MM(acc1o, ga.y, gb1.y); PFHIP_SB; PFHIP_GL(sb3, Wg, ldw, 3, knext); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.z, gb0.z); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.z, gb1.z); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc1o, ga.w, gb1.w); PFHIP_SB; \
+  PFHIP_MM(acc0e, fa.x, fb0.x); PFHIP_SB; PFHIP_FRA(ga, 1, 3); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.x, fb1.x); PFHIP_SB; PFHIP_FRB(gb0, 1, 3, 0); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.y, fb0.y); PFHIP_SB; PFHIP_FRB(gb1, 1, 3, 1); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.y, fb1.y); PFHIP_SB; \
+  PFHIP_MM(acc0e, fa.z, fb0.z); PFHIP_SB; PFHIP_SWA(ra0, As, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc1e, fa.z, fb1.z); PFHIP_SB; PFHIP_SWA(ra1, As, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc0o, fa.w, fb0.w); PFHIP_SB; PFHIP_SWB(rb0, Bs, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc1o, fa.w, fb1.w); PFHIP_SB; PFHIP_SWB(rb1, Bs, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.x, gb0.x); PFHIP_SB; PFHIP_SWB(rb2, Bs, 0, 2); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.x, gb1.x); PFHIP_SB; PFHIP_SWB(rb3, Bs, 0, 3); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.y, gb0.y); PFHIP_SB; __syncthreads(); \
+  PFHIP_MM(acc1o, ga.y, gb1.y); PFHIP_SB; PFHIP_FRA(fa, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc0e, ga.z, gb0.z); PFHIP_SB; PFHIP_FRB(fb0, 0, 0, 0); PFHIP_SB; \
+  PFHIP_MM(acc1e, ga.z, gb1.z); PFHIP_SB; PFHIP_FRB(fb1, 0, 0, 1); PFHIP_SB; \
+  PFHIP_MM(acc0o, ga.w, gb0.w); PFHIP_SB; \
+  PFHIP_MM(acc1o, ga.w, gb1.w); PFHIP_SB;
+
+  f32x16 acc0e, acc0o, acc1e, acc1o;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0e[e] = 0.f; acc0o[e] = 0.f; acc1e[e] = 0.f; acc1o[e] = 0.f; }
+  const int nk = K / kTileK;
+  {
+    int knext = 0;
+    PFHIP_GL(ra0, Ag, lda, 0, knext); PFHIP_GL(ra1, Ag, lda, 1, knext);
+    PFHIP_GL(rb0, Wg, ldw, 0, knext); PFHIP_GL(rb1, Wg, ldw, 1, knext); PFHIP_GL(rb2, Wg, ldw, 2, knext); PFHIP_GL(rb3, Wg, ldw, 3, knext);
+    PFHIP_SWA(ra0, As, 0, 0); PFHIP_SWA(ra1, As, 0, 1);
+    PFHIP_SWB(rb0, Bs, 0, 0); PFHIP_SWB(rb1, Bs, 0, 1); PFHIP_SWB(rb2, Bs, 0, 2); PFHIP_SWB(rb3, Bs, 0, 3);
+    knext = nk > 1 ? kTileK : 0;
+    PFHIP_GL(sa0, Ag, lda, 0, knext); PFHIP_GL(sa1, Ag, lda, 1, knext);
+    PFHIP_GL(sb0, Wg, ldw, 0, knext); PFHIP_GL(sb1, Wg, ldw, 1, knext); PFHIP_GL(sb2, Wg, ldw, 2, knext); PFHIP_GL(sb3, Wg, ldw, 3, knext);
+  }
+  __syncthreads();
+  const int a_off = (wr * 32 + r) * kLds + 4 * h;
+  const int b_off = (wc * 64 + r) * kLds + 4 * h;
+  PFHIP_FRA(fa, 0, 0); PFHIP_FRB(fb0, 0, 0, 0); PFHIP_FRB(fb1, 0, 0, 1);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    { const int knext = (kt + 2 < nk ? kt + 2 : nk - 1) * kTileK; PFHIP_BODY_0 }
+    { const int knext = (kt + 3 < nk ? kt + 3 : nk - 1) * kTileK; PFHIP_BODY_1 }
+  }
+  if (kt < nk) { const int knext = (nk - 1) * kTileK; PFHIP_BODY_0 }
+#undef PFHIP_BODY_0
+#undef PFHIP_BODY_1
+#undef PFHIP_SB
+#undef PFHIP_GL
+#undef PFHIP_SWA
+#undef PFHIP_SWB
+#undef PFHIP_FRA
+#undef PFHIP_FRB
+#undef PFHIP_MM
+
+  // ---- epilogue: accumulators -> LDS -> 512-byte rows (as the 128-row kernel) ----
+  __syncthreads();
+  float* const Cs = lds;
+  {
+    float* cw = Cs + (wr * 32 + 4 * h) * kCs + wc * 64 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ro = ((e & 3) + 8 * (e >> 2)) * kCs;
+      cw[ro] = acc0e[e] + acc0o[e];
+      cw[ro + 32] = acc1e[e] + acc1o[e];
+    }
+  }
+  __syncthreads();
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (HAS_BIAS) {
+    if (!GUARD || gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    else {
+      if (gcol < N) bv.x = bias[gcol];
+      if (gcol + 1 < N) bv.y = bias[gcol + 1];
+      if (gcol + 2 < N) bv.z = bias[gcol + 2];
+    }
+  }
+#pragma unroll 4
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 8 + rsub;
+    const int grow = m0 + row;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (!GUARD || (grow < M && gcol + 3 < N)) {
+      if (HAS_R1) {
+        const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (HAS_R2) {
+        const float4 t = *reinterpret_cast<const float4*>(R2 + (size_t)grow * ldr2 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+    } else if (grow < M && gcol < N) {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int q = 0; q < 4 && gcol + q < N; ++q) {
+        float o = vv[q];
+        if (HAS_R1) o += R1[(size_t)grow * ldr1 + gcol + q];
+        if (HAS_R2) o += R2[(size_t)grow * ldr2 + gcol + q];
+        if (RELU) o = fmaxf(o, 0.f);
+        C[(size_t)grow * ldc + gcol + q] = o;
+      }
+    }
+  }
+}
+
 // ---- skinny GEMM for the chunk-streaming path (M <= 64 rows: one 20-row encoder window, a few tokens) ----
 // Weight-streaming-bound: every weight is read once per chunk, so the job is to keep many independent
 // 16-byte loads in flight, not to tile for reuse.  One block = one 32-column strip of W over the full K,
@@ -408,6 +608,39 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(const float* __re
 }
 
 template <bool GUARD>
+void launch_variant64(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                      const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu,
+                      hipStream_t s) {
+  const int tiles_m = (M + kTileM64 - 1) / kTileM64;
+  const int tiles_n = (N + kTileN - 1) / kTileN;
+  const int n_tiles = tiles_m * tiles_n;
+  const dim3 grid(n_tiles), block(256);
+#define PFHIP_GEMM64(B_, R1_, R2_, RL_)                                                              \
+  hipLaunchKernelGGL((gemm_f32_mfma64_kernel<GUARD, B_, R1_, R2_, RL_>), grid, block, 0, s, A, lda, W, \
+                     ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles)
+  const int key = (bias ? 8 : 0) | (R1 ? 4 : 0) | (R2 ? 2 : 0) | (relu ? 1 : 0);
+  switch (key) {
+    case 0: PFHIP_GEMM64(false, false, false, false); break;
+    case 1: PFHIP_GEMM64(false, false, false, true); break;
+    case 2: PFHIP_GEMM64(false, false, true, false); break;
+    case 3: PFHIP_GEMM64(false, false, true, true); break;
+    case 4: PFHIP_GEMM64(false, true, false, false); break;
+    case 5: PFHIP_GEMM64(false, true, false, true); break;
+    case 6: PFHIP_GEMM64(false, true, true, false); break;
+    case 7: PFHIP_GEMM64(false, true, true, true); break;
+    case 8: PFHIP_GEMM64(true, false, false, false); break;
+    case 9: PFHIP_GEMM64(true, false, false, true); break;
+    case 10: PFHIP_GEMM64(true, false, true, false); break;
+    case 11: PFHIP_GEMM64(true, false, true, true); break;
+    case 12: PFHIP_GEMM64(true, true, false, false); break;
+    case 13: PFHIP_GEMM64(true, true, false, true); break;
+    case 14: PFHIP_GEMM64(true, true, true, false); break;
+    default: PFHIP_GEMM64(true, true, true, true); break;
+  }
+#undef PFHIP_GEMM64
+}
+
+template <bool GUARD>
 void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                     const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu,
                     hipStream_t s) {
@@ -455,11 +688,20 @@ void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, 
 
 }  // namespace
 
-// Launches with fewer 128 x 128 tiles than this take the weight-streaming kernel (one block per 32 x 32 output patch, 16
-// waves splitting K): a 128 x 128 tile walks its whole K range serially (34 us for K = 512, 120 us for K = 2048) and a
-// grid that does not fill the 256 CUs cannot hide that.  Measured crossover (tools/gemm_sweep.py): 120-132 tiles for
-// every (N, K) of the model — one 30-s utterance (M = 500) or a batch of streaming windows is 2-7x faster this way.
-constexpr int kStreamingBelowTiles = 128;
+// Which kernel: measured on the model's (N, K) over M = 32 ... 16000 (tools/gemm_sweep.py).  A launch runs in ROUNDS of one
+// block per CU (a second co-resident block does not shorten a round), a 128 x 128 tile costs ~34 us per round at K = 512
+// (~120 us at K = 2048), a 64 x 128 tile 0.55 of that, and the weight-streaming kernel (32 x 32 patches, 16 waves splitting K)
+// ~9 us per round of patches.  Hence: below 64 tiles the streaming kernel (one 30-s utterance, streaming windows: 2-7x faster
+// than a lone 128 x 128 tile walking its K range serially); up to 128 tiles the 64-row kernel (one round instead of a
+// half-empty one: -40 %); above that whichever of the two tilings needs less round time (the 64-row one wins where the
+// 128-row grid would leave most of its last round empty, e.g. 257-384 tiles: -14 %).
+constexpr int kCUs = 256;
+constexpr int kStreamingBelowTiles = 64;
+inline bool prefer_half_tile(int tiles128) {
+  if (tiles128 <= 128) return true;
+  const int r128 = (tiles128 + kCUs - 1) / kCUs, r64 = (2 * tiles128 + kCUs - 1) / kCUs;
+  return 0.55 * r64 < 0.98 * r128;
+}
 
 void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                           int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, bool guard, int kind,
@@ -467,10 +709,16 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
   if (M <= 0 || N <= 0) return;
   const int tiles = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
   const bool skinny = kind == 2 || (kind == 0 && tiles < kStreamingBelowTiles);
+  const bool half = kind == 3 || (kind == 0 && prefer_half_tile(tiles));
   if (skinny) {   // always bounds-checked
     const dim3 grid((N + 31) / 32, (M + 31) / 32), block(1024);
     hipLaunchKernelGGL(gemm_f32_skinny_kernel, grid, block, 0, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N,
                        K, relu ? 1 : 0);
+    return;
+  }
+  if (half) {
+    if (guard) launch_variant64<true>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
+    else launch_variant64<false>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);
     return;
   }
   if (guard) launch_variant<true>(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, s);

@@ -118,10 +118,57 @@ def emit_half(name, cur):
     return f"#define LOOP_BODY_{name}_{cur} \\\n" + " \\\n".join("  " + l for l in lines) + "\n"
 
 
+# ---- 64 x 128 block tile (4 waves as 2 x 2, each 32 x 64 = 1 x 2 MFMA tiles) -------------------------------------------
+# Used for launches that would give too few 128 x 128 tiles to fill the chip.  Per wave and K-tile: 32 MFMAs (4 k-blocks x 8),
+# 6 global loads (A rows lrow, lrow+32; W rows lrow + 32 j), 12 fragment reads (A, B0, B1 per k-block), 6 LDS writes.
+# Four accumulators (two output tiles x even/odd k-pairs) so that an accumulator is reused every 4th MFMA.
+def emit64(cur):
+    regs = [["ra0", "ra1", "rb0", "rb1", "rb2", "rb3"], ["sa0", "sa1", "sb0", "sb1", "sb2", "sb3"]]
+    lset, sset = cur, 1 - cur          # prefetch distance 2, as schedule H
+
+    def G(j):
+        base, ld, jj = ("Ag", "lda", j) if j < 2 else ("Wg", "ldw", j - 2)
+        return f"GL({regs[lset][j]}, {base}, {ld}, {jj}, knext);"
+
+    def W(j):
+        base, jj = ("As", j) if j < 2 else ("Bs", j - 2)
+        return f"SW{'A' if j < 2 else 'B'}({regs[sset][j]}, {base}, {cur ^ 1}, {jj});"
+
+    def R(k, j):                       # j: 0 = A, 1 = B0, 2 = B1
+        s = "f" if k % 2 == 0 else "g"
+        buf, kb = (cur ^ 1, 0) if k == 4 else (cur, k)
+        if j == 0:
+            return f"FRA({s}a, {buf}, {kb});"
+        return f"FRB({s}b{j - 1}, {buf}, {kb}, {j - 1});"
+
+    table = {0: {0: [R(1, 0)], 1: [R(1, 1)], 2: [R(1, 2)], 3: [G(0)], 4: [G(1)], 5: [G(2)], 6: [G(3)], 7: [G(4)]},
+             1: {0: [R(2, 0)], 1: [R(2, 1)], 2: [R(2, 2)], 3: [G(5)]},
+             2: {0: [R(3, 0)], 1: [R(3, 1)], 2: [R(3, 2)], 4: [W(0)], 5: [W(1)], 6: [W(2)], 7: [W(3)]},
+             3: {0: [W(4)], 1: [W(5)], 3: [R(4, 0)], 4: [R(4, 1)], 5: [R(4, 2)]}}
+    barrier = (3, 2)
+    lines = []
+    for g in range(4):
+        s = "f" if g % 2 == 0 else "g"
+        for i in range(8):
+            c = "xyzw"[i // 2]
+            par = "e" if (i // 2) % 2 == 0 else "o"
+            t = i % 2
+            line = f"MM(acc{t}{par}, {s}a.{c}, {s}b{t}.{c}); SB;"
+            for op in table.get(g, {}).get(i, []):
+                line += " " + op + " SB;"
+            if (g, i) == barrier:
+                line += " __syncthreads();"
+            lines.append(line)
+    return f"#define LOOP_BODY_T64_{cur} \\\n" + " \\\n".join("  " + l for l in lines) + "\n"
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or sorted(SCHEDULES)
+    names = [n for n in sys.argv[1:] if n != "T64"] or (sorted(SCHEDULES) if len(sys.argv) == 1 else [])
     print("// generated by gen_gemm_loop.py — do not edit")
     for n in names:
         print(emit(n))
     for n in names:
         print(f"#define LOOP_PF_{n} {SCHEDULES[n][2]}")
+    if "T64" in sys.argv[1:] or len(sys.argv) == 1:
+        print(emit64(0))
+        print(emit64(1))

@@ -33,6 +33,26 @@ constexpr int kCs = kTileN + 4;                // padded C-tile row stride (floa
 constexpr int kLdsFloats = 4 * kStage;         // 73,728 B: A0 A1 B0 B1; the C tile (128 x 132) reuses it
 static_assert(kTileM * kCs <= kLdsFloats, "C tile must fit the operand buffers");
 
+// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): blocks that share an XCD (equal blockIdx % 8) walk a
+// contiguous run of a linear tile order.  That order is column-GROUP major: group g = column tiles [g*gw, (g+1)*gw), inside
+// a group row panel by row panel, n fastest — so the gw weight tiles of a group (<= 2 MiB, the host picks gw) stay in the
+// XCD's 4 MB L2 while its row panels stream through, instead of the whole weight matrix being re-fetched for every
+// handful of row panels.  Same time, 35-70 % less L2->fabric traffic on the wide GEMMs (tools/probe/gemm_sched.hip + PMC).
+__device__ __forceinline__ void tile_of_block(int bid, int n_tiles, int tiles_n, int gw, int& tm, int& tn) {
+  {
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tiles_m = n_tiles / tiles_n, full = tiles_n / gw, span = tiles_m * gw;
+  if (bid < full * span) {
+    const int g = bid / span, j = bid - g * span;
+    tm = j / gw; tn = g * gw + (j - tm * gw);
+  } else {                                        // the last, narrower group
+    const int j = bid - full * span, w = tiles_n - full * gw;
+    tm = j / w; tn = full * gw + (j - tm * w);
+  }
+}
+
 template <bool GUARD, bool HAS_BIAS, bool HAS_R1, bool HAS_R2, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
@@ -42,27 +62,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
   float* const As = lds;                  // [2][128][36]
   float* const Bs = lds + 2 * kStage;     // [2][128][36]
 
-  // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): blocks that share an XCD (equal blockIdx % 8) walk a
-  // contiguous run of a linear tile order.  That order is column-GROUP major: group g = column tiles [g*gw, (g+1)*gw), inside
-  // a group row panel by row panel, n fastest — so the gw weight tiles of a group (<= 2 MB, the host picks gw) stay in the
-  // XCD's 4 MB L2 while its row panels stream through, instead of the whole weight matrix being re-fetched for every
-  // handful of row panels.  Same time, 35-70 % less L2->fabric traffic on the wide GEMMs (tools/probe/gemm_sched.hip + PMC).
-  int bid = blockIdx.x;
-  {
-    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   int tm, tn;
-  {
-    const int tiles_m = n_tiles / tiles_n, full = tiles_n / gw, span = tiles_m * gw;
-    if (bid < full * span) {
-      const int g = bid / span, j = bid - g * span;
-      tm = j / gw; tn = g * gw + (j - tm * gw);
-    } else {                                        // the last, narrower group
-      const int j = bid - full * span, w = tiles_n - full * gw;
-      tm = j / w; tn = full * gw + (j - tm * w);
-    }
-  }
+  tile_of_block(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
   const int m0 = tm * kTileM, n0 = tn * kTileN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -337,16 +338,12 @@ template <bool GUARD, bool HAS_BIAS, bool HAS_R1, bool HAS_R2, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma64_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N,
-    int K, int tiles_n, int n_tiles) {
+    int K, int tiles_n, int n_tiles, int gw) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats64];
   float* const As = lds;                      // [2][64][36]
   float* const Bs = lds + 2 * kStageA64;      // [2][128][36]
-  int bid = blockIdx.x;
-  {
-    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  tile_of_block(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
   const int m0 = tm * kTileM64, n0 = tn * kTileN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -607,6 +604,24 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(const float* __re
   C[(size_t)grow * ldc + gcol] = v;
 }
 
+// column-group width of the tile order (see tile_of_block), from a small traffic model that reproduces the PMC numbers
+// (profiles/r01/pmc_hbm_traffic.json) within ~30 %: per XCD, `rows_conc` row panels are in flight at once (64 block slots);
+//   all columns in one group: A is fetched once, the weights once per XCD per PASS over its row panels
+//                             (passes = row panels of the XCD / rows_conc) when they do not fit the L2 share, else once;
+//   groups of g column tiles (<= 2 MiB of weights, resident): A once per group, the weights once per XCD.
+inline int column_group_width(int M, int K, int tiles_n) {
+  constexpr double kL2Share = 2.0 * 1024 * 1024;
+  const double wt = (double)kTileN * K * 4, w_total = wt * tiles_n, a_total = (double)M * K * 4;
+  if (w_total <= kL2Share) return tiles_n;
+  const int g = std::max(1, (int)(kL2Share / wt));
+  if (g >= tiles_n) return tiles_n;
+  const double tiles_m = (M + kTileM - 1) / kTileM;
+  const double rows_conc = std::max(1.0, 64.0 / tiles_n), passes = std::max(1.0, tiles_m / 8.0 / rows_conc);
+  const int groups = (tiles_n + g - 1) / g;
+  const double est_all = a_total + w_total * 8 * passes, est_grouped = a_total * groups + w_total * 8;
+  return est_grouped < est_all ? g : tiles_n;
+}
+
 template <bool GUARD>
 void launch_variant64(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                       const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu,
@@ -615,9 +630,10 @@ void launch_variant64(const float* A, int lda, const float* W, int ldw, float* C
   const int tiles_n = (N + kTileN - 1) / kTileN;
   const int n_tiles = tiles_m * tiles_n;
   const dim3 grid(n_tiles), block(256);
+  const int gw = column_group_width(M, K, tiles_n);
 #define PFHIP_GEMM64(B_, R1_, R2_, RL_)                                                              \
   hipLaunchKernelGGL((gemm_f32_mfma64_kernel<GUARD, B_, R1_, R2_, RL_>), grid, block, 0, s, A, lda, W, \
-                     ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles)
+                     ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw)
   const int key = (bias ? 8 : 0) | (R1 ? 4 : 0) | (R2 ? 2 : 0) | (relu ? 1 : 0);
   switch (key) {
     case 0: PFHIP_GEMM64(false, false, false, false); break;
@@ -648,19 +664,7 @@ void launch_variant(const float* A, int lda, const float* W, int ldw, float* C, 
   const int tiles_n = (N + kTileN - 1) / kTileN;
   const int n_tiles = tiles_m * tiles_n;
   const dim3 grid(n_tiles), block(256);
-  // column-group width of the tile order (see the kernel): all columns when the whole weight matrix sits comfortably in an
-  // L2 (<= 2 MB); else as many column tiles as fit 2 MB, unless re-reading the activations once per group costs more than
-  // the weight re-fetches it saves
-  int gw = tiles_n;
-  {
-    const double wt = (double)kTileN * K * 4, w_total = wt * tiles_n, a_total = (double)M * K * 4;
-    constexpr double kL2Share = 2.0 * 1024 * 1024;
-    if (w_total > kL2Share) {
-      const int g = std::max(1, (int)(kL2Share / wt));
-      const int groups = (tiles_n + g - 1) / g;
-      if (g < tiles_n && a_total * (groups - 1) < w_total * 8 * 3) gw = g;
-    }
-  }
+  const int gw = column_group_width(M, K, tiles_n);
 #define PFHIP_GEMM(B_, R1_, R2_, RL_)                                                              \
   hipLaunchKernelGGL((gemm_f32_mfma_kernel<GUARD, B_, R1_, R2_, RL_>), grid, block, 0, s, A, lda, W, \
                      ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw)

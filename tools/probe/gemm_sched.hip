@@ -15,6 +15,7 @@ constexpr int kLds = 36, kStage = 128 * kLds, kCs = 132;
 #define MM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
 __constant__ int g_gw;
+__constant__ int g_delay;
 #define KERNEL(NAME)                                                                                                          \
   __global__ __launch_bounds__(256, 2) void gemm_##NAME(const float* __restrict__ A, const float* __restrict__ W, float* C,   \
                                                         int lda, int ldw, int ldc, int nk, int tiles_n, int n_tiles) {        \
@@ -33,6 +34,7 @@ __constant__ int g_gw;
     const int lrow = tid >> 3, lc4 = tid & 7;                                                                                 \
     const float* Ag = A + (size_t)(m0 + lrow) * lda + 4 * lc4;                                                                \
     const float* Wg = W + (size_t)(n0 + lrow) * ldw + 4 * lc4;                                                                \
+    if (g_delay > 0 && ((blockIdx.x >> 8) & 1)) for (int q_ = 0; q_ < g_delay; ++q_) __builtin_amdgcn_s_sleep(127);           \
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;                                    \
     f32x16 acc00, acc01, acc10, acc11;                                                                                        \
     for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }                          \
@@ -108,8 +110,9 @@ KERNEL(A_nosw)
 
 typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int);
 static kern_t kernels[] = {gemm_H, gemm_H, gemm_H, gemm_H, gemm_H, gemm_H};
-static int gws[] = {0, 8, 4, 2, 1, 6};
-static const char* names[] = {"H", "gw8", "gw4", "gw2", "gw1", "gw6"};
+static int gws[] = {0, 0, 0, 0, 0, 0};
+static int delays[] = {0, 1, 2, 4, 6, 0};
+static const char* names[] = {"H", "d3us", "d7us", "d14us", "d20us", "H"};
 
 float run(kern_t k, const float* A, const float* W, float* C, int M, int N, int K, int iters) {
   const int tiles_n = N / 128, blocks = (M / 128) * tiles_n;
@@ -143,6 +146,7 @@ int main() {
     for (int rep = 0; rep < 4; ++rep)            // variants interleaved: clock ramp / thermal drift hits all of them alike
       for (int v = 0; v < nv; ++v) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_gw), &gws[v], sizeof(int));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_delay), &delays[v], sizeof(int));
         const float t = run(kernels[v], A, W, C, M, N, K, 30);
         if (rep > 0) best[v] = fminf(best[v], t);
       }

@@ -166,3 +166,26 @@ def test_cross_request_batching_matches_separate_calls(small):
         if a["logp"] is not None:
             for x, y in zip(a["logp"], g["logp"]):
                 assert np.abs(x - y).max() < 1e-4
+
+
+def test_full_size_batch_matches_oracle(pkg, weights_mod):
+    """BASELINE configs[1] exactly — Paraformer-large, 32 x 30 s in one packed forward (every GEMM on the 128 x 128 tiled
+    kernel, M = 16000) — against the CPU restatement for two of the utterances: token ids identical, log-probs within the
+    1e-3 that north_star states (measured ~1e-5)."""
+    cfg = dict(weights_mod.PARAFORMER_LARGE)
+    man, blob = weights_mod.synth_weights(cfg)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    W = P.Weights(man, blob)
+    rng = np.random.default_rng(20251114)
+    utts = [synth_pcm(i, 480000, rng) for i in range(32)]
+    got = model.forward_ids(utts, want_logp=True)
+    for i in (3, 31):
+        ref = P.forward_pcm(utts[i], W)
+        assert int(got["token_num"][i]) == ref["token_num"]
+        assert list(got["ids"][i]) == list(ref["ids"])
+        n = min(len(got["logp"][i]), len(ref["logp"]))
+        assert n > 50
+        err = np.abs(got["logp"][i][:n] - ref["logp"][:n]).max()
+        assert err < 1e-3, err
+        assert err < 1e-4, err            # what fp32 end to end actually gives
+    model.close()

@@ -62,7 +62,8 @@ pfhip_status stream_alloc(pfhip_stream* s) {
   HIP_TRY(s->carry.ensure((size_t)(d + 4) * 4));
   HIP_TRY(s->dcache.ensure((size_t)std::max(1, m->cfg.dec_layers) * 10 * d * 4));
   HIP_TRY(s->meta.ensure(256));
-  HIP_TRY(hipHostMalloc((void**)&s->h_pin, 4096, hipHostMallocDefault));
+  // pinned: 4 KB of control words, then the PCM staging area of one call (no host sync between the connections of a batch)
+  HIP_TRY(hipHostMalloc((void**)&s->h_pin, 4096 + (size_t)(kMaxSamples + 1024) * 4, hipHostMallocDefault));
   return PFHIP_OK;
 }
 
@@ -338,8 +339,11 @@ pfhip_status extract_feats(pfhip_stream* s, const float* pcm, int len, bool inpu
     const int base = fresh ? (lfr_m - 1) / 2 : s->n_splice;
     if (used > kMaxSamples + 1024 || base + frame_number > kMaxFrames)
       return fail(PFHIP_ERR_ARG, "too many samples in one streaming call");
-    HIP_TRY(hipMemcpyAsync(s->pcm.p, waves.data(), (size_t)used * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));          // `waves` is pageable host memory that dies with this scope
+    // through this connection's pinned staging area: the copy is truly asynchronous and `waves` may die with this scope;
+    // the area is next written by this connection's next call, after the forward of this one has synchronised
+    float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(s->h_pin) + 4096);
+    std::memcpy(stage, waves.data(), (size_t)used * 4);
+    HIP_TRY(hipMemcpyAsync(s->pcm.p, stage, (size_t)used * 4, hipMemcpyHostToDevice, st));
     float* fb = s->fb[s->fb_cur].f();
     {
       int64_t* hm64 = reinterpret_cast<int64_t*>(s->h_pin + 768);

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
     "pfhip_timestamp_onnx",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
-    "pfhip_punc_infer_online",
+    "pfhip_punc_infer_online", "pfhip_punc_add_punc",
 ]
 
 
@@ -121,6 +121,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_punc_num_classes.argtypes = [vp]
     lib.pfhip_punc_infer.argtypes = [vp, vp, ci, vp, vp]
     lib.pfhip_punc_infer_online.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.pfhip_punc_add_punc.argtypes = [vp, vp, ci, vp, ci, ctypes.POINTER(ci)]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -498,6 +499,15 @@ class CTTransformerHip:
             self.close()
         except Exception:
             pass
+
+    def AddPuncIds(self, input_data):
+        """The id-level part of CTTransformer::AddPunc (ct-transformer.cpp:39-155): punctuation id per token (+ one appended
+        period when the text does not end a sentence)."""
+        ids = np.ascontiguousarray(input_data, dtype=np.int32)
+        out = np.zeros(ids.size + 1, np.int32)
+        n = ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_punc_add_punc(self._h, ids.ctypes.data, int(ids.size), out.ctypes.data, int(out.size), ctypes.byref(n)))
+        return out[:n.value].copy()
 
     def Infer(self, input_data, want_logits=False, nCacheSize=None):
         """nCacheSize=None: CTTransformer::Infer; an int: CTTransformerOnline::Infer(input_data, nCacheSize)."""

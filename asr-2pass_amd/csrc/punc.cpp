@@ -224,3 +224,51 @@ static pfhip_status punc_infer_impl(pfhip_punc* p, const int32_t* ids, int n, in
 }
 
 }  // extern "C"
+
+// ---- AddPunc's mini-sentence bookkeeping on token ids (ct-transformer.cpp:39-155) --------------------
+// The text side of AddPunc (tokeniser, joining words and punctuation strings, en-bpe symbol mapping) stays above this call;
+// what is restated here decides WHICH ids each Infer sees and which punctuation every token finally gets: 20-token
+// mini-sentences, the un-punctuated tail of a mini-sentence carried into the next one (RemainIDs), a forced period at the
+// last comma once the carried text exceeds CACHE_POP_TRIGGER_LIMIT, and the sentence-final fix-up of the last token.
+pfhip_status pfhip_punc_add_punc(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, int cap, int* n_out) {
+  last_error().clear();
+  if (!p || !ids || n < 0 || !punc_out || !n_out) return fail(PFHIP_ERR_ARG, "bad argument");
+  constexpr int kTokenLen = 20, kCachePopTriggerLimit = 200;           // com-define.h:126,136
+  constexpr int kNotPunc = 1, kComma = 2, kPeriod = 3, kQuestion = 4, kDun = 5;   // com-define.h:131-135
+  *n_out = 0;
+  std::vector<int32_t> remain, out;
+  const int total_batch = (n + kTokenLen - 1) / kTokenLen;
+  for (int i = 0; i < n; i += kTokenLen) {
+    const int take = std::min(kTokenLen, n - i);
+    std::vector<int32_t> input(remain);
+    input.insert(input.end(), ids + i, ids + i + take);
+    std::vector<int32_t> punc(input.size());
+    pfhip_status st = punc_infer_impl(p, input.data(), (int)input.size(), -1, punc.data(), nullptr);
+    if (st) return st;
+    const int cur_batch = i / kTokenLen;
+    if (cur_batch < total_batch - 1) {                                // not the last mini-sentence (:66-90)
+      int sent_end = -1, last_comma = -1;
+      for (int k = (int)punc.size() - 2; k > 0; --k) {
+        if (punc[k] == kPeriod || punc[k] == kQuestion) { sent_end = k; break; }
+        if (last_comma < 0 && punc[k] == kComma) last_comma = k;
+      }
+      if (sent_end < 0 && (int)input.size() > kCachePopTriggerLimit && last_comma > 0) {
+        sent_end = last_comma;
+        punc[sent_end] = kPeriod;
+      }
+      remain.assign(input.begin() + (sent_end + 1), input.end());
+      punc.resize((size_t)(sent_end + 1));
+    }
+    out.insert(out.end(), punc.begin(), punc.end());
+  }
+  if (!out.empty()) {                                                 // last mini-sentence (:112-127)
+    const int last = out.back();
+    if (last == kComma || last == kDun) out.back() = kPeriod;
+    else if (last != kPeriod && last != kQuestion) out.push_back(kPeriod);   // a period is APPENDED after the last token
+  }
+  (void)kNotPunc;
+  if ((int)out.size() > cap) return fail(PFHIP_ERR_CAPACITY, "punc_out too small (needs up to n + 1)");
+  std::copy(out.begin(), out.end(), punc_out);
+  *n_out = (int)out.size();
+  return PFHIP_OK;
+}

@@ -219,6 +219,12 @@ pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t*
  * look-ahead is the container's `sanm_shift` (0 or 5). */
 pfhip_status pfhip_punc_infer_online(pfhip_punc* p, const int32_t* ids, int n, int cache_size, int32_t* punc_out,
                                      float* logits_out);
+/* AddPunc's mini-sentence loop on token ids (ct-transformer.cpp:39-155): 20-token mini-sentences, the tail after the last
+ * sentence end carried into the next Infer, forced period at the last comma beyond CACHE_POP_TRIGGER_LIMIT carried tokens,
+ * sentence-final fix-up.  punc_out receives one punctuation id per token and, when the text does not end in "。"/"？", one
+ * extra PERIOD_INDEX (the reference appends the character): *n_out = n or n + 1 (cap >= n + 1).  The tokeniser and the
+ * string assembly stay on the host above this. */
+pfhip_status pfhip_punc_add_punc(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, int cap, int* n_out);
 
 /* ---- inspection (parity tests) -----------------------------------------------------------------
  * Copies a named intermediate of the LAST forward to host: "feats" [M,560], "enc" [M,d],

@@ -93,3 +93,37 @@ def forward_online(ids, W, vad_pos):
     x = P.layer_norm(x, W["enc.after_norm.g"], W["enc.after_norm.b"])
     logits = P.linear(x, W["out.w"], W["out.b"])
     return logits, np.argmax(logits[:, :cfg["n_punc"] - 1], axis=-1).astype(np.int32)
+
+
+def add_punc_ids(ids, W, infer_fn=None):
+    """CTTransformer::AddPunc (ct-transformer.cpp:39-155) on token ids: returns the punctuation id list NewPuncOut."""
+    TOKEN_LEN, CACHE_POP_TRIGGER_LIMIT = 20, 200
+    COMMA, PERIOD, QUESTION, DUN = 2, 3, 4, 5
+    infer_fn = infer_fn or (lambda x: list(infer(x, W)[1]))
+    ids = [int(v) for v in ids]
+    n = len(ids)
+    total = -(-n // TOKEN_LEN)
+    remain, new_punc = [], []
+    for i in range(0, n, TOKEN_LEN):
+        inp = remain + ids[i:i + TOKEN_LEN]
+        punc = [int(v) for v in infer_fn(inp)]
+        if i // TOKEN_LEN < total - 1:
+            sent_end, last_comma = -1, -1
+            for k in range(len(punc) - 2, 0, -1):
+                if punc[k] in (PERIOD, QUESTION):
+                    sent_end = k
+                    break
+                if last_comma < 0 and punc[k] == COMMA:
+                    last_comma = k
+            if sent_end < 0 and len(inp) > CACHE_POP_TRIGGER_LIMIT and last_comma > 0:
+                sent_end = last_comma
+                punc[sent_end] = PERIOD
+            remain = inp[sent_end + 1:]
+            punc = punc[:sent_end + 1]
+        new_punc += punc
+    if new_punc:
+        if new_punc[-1] in (COMMA, DUN):
+            new_punc[-1] = PERIOD
+        elif new_punc[-1] not in (PERIOD, QUESTION):
+            new_punc.append(PERIOD)
+    return new_punc

@@ -78,3 +78,22 @@ def test_online_variant_with_vad_mask(pkg, weights_mod, shift):
     _, b = h.Infer(ids, want_logits=True, nCacheSize=0)
     assert np.abs(a[:20] - b[:20]).max() > 1e-3
     h.close()
+
+
+def test_add_punc_mini_sentences(pkg, weights_mod):
+    """AddPunc's id-level loop (20-token mini-sentences, carried tail, forced period beyond 200 carried tokens, final
+    fix-up) against the restatement, with output biases that make sentence ends rare (long carries) or common."""
+    for bias, seed in (((0.0, 3.0, 1.5, -3.0, -3.0, 0.0), 5), ((0.0, 2.0, 0.0, 1.0, 0.5, 0.0), 6), ((0.0, 4.0, 0.0, -6.0, -6.0, 0.0), 7)):
+        cfg = dict(weights_mod.CT_TRANSFORMER, vocab=2000)
+        man, blob = weights_mod.synth_punc_weights(cfg, seed=seed)
+        W = P.Weights(man, blob)
+        W["out.b"][:] = np.asarray(bias, np.float32)          # classes: unk, not-punc, comma, period, question, dun
+        h = pkg.CTTransformerHip().InitPunc((man, blob))
+        rng = np.random.default_rng(seed)
+        for n in (1, 19, 20, 21, 75, 260, 431):
+            ids = rng.integers(0, 2000, n).astype(np.int32)
+            got = h.AddPuncIds(ids)
+            ref = C.add_punc_ids(ids, W)
+            assert list(got) == ref, (bias, n)
+            assert len(ref) in (n, n + 1) and ref[-1] in (3, 4)
+        h.close()

@@ -42,6 +42,15 @@ def main():
     z = np.zeros(1000, np.int16)
     z[500] = 1
     np.savez_compressed(os.path.join(HERE, "fbank_floor.npz"), pcm=z, fbank=ref_fbank(z.astype(np.float32) / 32768))
+    # (4) the reference's other two samples: 1.0-s excerpts (English speech with music bed; spoken digits incl. a loud onset)
+    for name, start in (("SteveJobs_10s", 40000), ("number", 30000)):
+        wf = wave.open(f"/root/reference/clients/audio/{name}.wav")
+        x = np.frombuffer(wf.readframes(wf.getnframes()), np.int16)
+        seg = x[start:start + 16000].copy()
+        np.savez_compressed(os.path.join(HERE, f"fbank_{name.lower()}.npz"), pcm=seg, fbank=ref_fbank(seg.astype(np.float32) / 32768))
+    # (5) full-scale clipping: a +-32767 square wave (largest magnitudes the front end can see)
+    sq = np.where((np.arange(4000) // 37) % 2 == 0, 32767, -32768).astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, "fbank_fullscale.npz"), pcm=sq, fbank=ref_fbank(sq.astype(np.float32) / 32768))
     print("golden fixtures written")
 
 

@@ -27,7 +27,7 @@ def small(pkg, weights_mod):
     model.close()
 
 
-@pytest.mark.parametrize("name", ["fbank_synth", "fbank_xmov", "fbank_floor"])
+@pytest.mark.parametrize("name", ["fbank_synth", "fbank_xmov", "fbank_floor", "fbank_stevejobs_10s", "fbank_number", "fbank_fullscale"])
 def test_feats_match_reference_golden(small, name):
     """fbank from the REFERENCE's knf (golden) -> oracle LFR/CMVN  vs  the fused HIP kernel."""
     model, W = small

@@ -19,7 +19,7 @@ GOLD = os.path.join(HERE, "golden")
 FBANK_TOL = 4e-6
 
 
-@pytest.mark.parametrize("name", ["fbank_synth", "fbank_xmov", "fbank_floor"])
+@pytest.mark.parametrize("name", ["fbank_synth", "fbank_xmov", "fbank_floor", "fbank_stevejobs_10s", "fbank_number", "fbank_fullscale"])
 def test_fbank_matches_reference_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     got = fe.fbank(g["pcm"].astype(np.float32) / 32768)

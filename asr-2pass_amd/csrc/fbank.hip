@@ -212,6 +212,13 @@ void launch_fbank_frames(const float* pcm, const int64_t* sample_off, const int*
   hipLaunchKernelGGL(fbank_lfr_cmvn_kernel, dim3((total_frames + 3) / 4), dim3(256), 0, s, p);
 }
 
+void launch_fbank_frames_batch(const float* pcm, const int64_t* sample_off, const int* frame_off, const int* nframes, int B,
+                               int total_frames, FbankTables tb, float* fb_out, hipStream_t s) {
+  if (total_frames <= 0) return;
+  FbankParams p{pcm, sample_off, frame_off, nframes, nullptr, B, total_frames, tb, nullptr, fb_out};
+  hipLaunchKernelGGL(fbank_lfr_cmvn_kernel, dim3((total_frames + 3) / 4), dim3(256), 0, s, p);
+}
+
 // ---- embed: x*sqrt(d_model) + sinusoidal PE (paraformer-online.cpp:549-555, 240-268) ----------
 namespace {
 __global__ __launch_bounds__(192) void embed_kernel(const float* feats, int D, float* x0, int ldx,

@@ -32,6 +32,9 @@ void launch_fbank_lfr_cmvn(const float* pcm, const int64_t* sample_off, const in
 // log-mel frames [total_frames, 80] out, no LFR/CMVN.  sample_off/frame_off/nframes: 1/2/1 entries.
 void launch_fbank_frames(const float* pcm, const int64_t* sample_off, const int* frame_off, const int* nframes,
                          int total_frames, FbankTables tb, float* fb_out, hipStream_t s);
+// the same for B utterances back to back in `pcm` (frame_off has B + 1 entries); frames land back to back in fb_out
+void launch_fbank_frames_batch(const float* pcm, const int64_t* sample_off, const int* frame_off, const int* nframes, int B,
+                               int total_frames, FbankTables tb, float* fb_out, hipStream_t s);
 
 // x0[row][0..D) = feats*scale + PE(row_pos[row]+1); columns D..ldx are zeroed.
 void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_pos, int M,
@@ -135,8 +138,12 @@ void launch_stream_lfr(const float* fb, int T, int n_rows, const float* mean, co
                        const float* inv_ts, int pos0, float* out, int ldo, hipStream_t s);
 // dst[r][0..ncols) = src[r][0..ncols) (or 0 when src == nullptr), columns ncols..ldd zeroed.
 void launch_rows_copy(float* dst, int ldd, const float* src, int lds_, int nrows, int ncols, hipStream_t s);
-// CifSearch (paraformer-online.cpp:270-345): carry (hidden,alpha) prepended, alphas[0:pre) and [suf:)
-// zeroed, optional tail; fired frames -> emb rows, *n_fire; carry updated in place.
+// The same two for many connections in one launch: one descriptor per operation (arrays in HBM).
+struct RowsCopyOp { float* dst; const float* src; int ldd, lds, nrows, ncols; };      // src == nullptr: zeros; lds == 0: row 0 repeated
+struct StreamLfrOp { const float* fb; float* out; int T, n_rows, pos0, pad_; };
+void launch_rows_copy_batch(const RowsCopyOp* ops, int n_ops, int max_rows, hipStream_t s);
+void launch_stream_lfr_batch(const StreamLfrOp* ops, int n_ops, int max_rows, const float* mean, const float* istd, float scale,
+                             const float* inv_ts, int ldo, hipStream_t s);
 // One connection of a streaming batch (device-side descriptor): its window in the packed encoder matrices, its tokens in
 // the packed decoder matrices (filled in after the CIF counts are known), and its persistent state.
 struct StreamSeg {

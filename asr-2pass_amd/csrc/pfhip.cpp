@@ -739,13 +739,14 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
                   (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
+  if (m->h_ops) (void)hipHostFree(m->h_ops);
   if (m->h_counts) (void)hipHostFree(m->h_counts);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);

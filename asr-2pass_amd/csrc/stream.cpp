@@ -28,14 +28,14 @@ struct pfhip_stream {
   int chunk_size[3] = {5, 10, 5};
   // host state
   std::vector<float> input_cache;
+  std::vector<float> waves;    // input_cache_ ++ this call's samples, alive until the batched upload has copied it
   int n_splice = 0;            // frames in the splice cache (front of fb[cur])
   int start_idx = 0;           // start_idx_cache_
   bool is_first_chunk = true, is_last_chunk = false;
   int n_featc = 10;            // rows in feats_cache_
   // device state
-  Buf pcm, fb[2], rows, featc, chunk, carry, dcache, meta;
+  Buf fb[2], rows, featc, chunk, carry, dcache;
   int fb_cur = 0;
-  int* h_pin = nullptr;        // pinned: [0] n_fire, [1..] ids
   // the window waiting in `chunk` for the next batched forward
   int win_n = 0;
   // last chunk (inspection): where its rows / tokens sit in the model's packed workspace
@@ -54,16 +54,12 @@ constexpr int kMaxTok = 72;
 pfhip_status stream_alloc(pfhip_stream* s) {
   pfhip_model* m = s->m;
   const int d = m->cfg.d_model, FD = m->feat_dim, FP = m->feat_pad;
-  HIP_TRY(s->pcm.ensure((size_t)(kMaxSamples + 1024) * 4));
   for (int i = 0; i < 2; ++i) HIP_TRY(s->fb[i].ensure((size_t)kMaxFrames * 80 * 4));
   HIP_TRY(s->rows.ensure((size_t)kMaxRows * FD * 4));
   HIP_TRY(s->featc.ensure((size_t)16 * FD * 4));
   HIP_TRY(s->chunk.ensure((size_t)128 * FP * 4));
   HIP_TRY(s->carry.ensure((size_t)(d + 4) * 4));
   HIP_TRY(s->dcache.ensure((size_t)std::max(1, m->cfg.dec_layers) * 10 * d * 4));
-  HIP_TRY(s->meta.ensure(256));
-  // pinned: 4 KB of control words, then the PCM staging area of one call (no host sync between the connections of a batch)
-  HIP_TRY(hipHostMalloc((void**)&s->h_pin, 4096 + (size_t)(kMaxSamples + 1024) * 4, hipHostMallocDefault));
   return PFHIP_OK;
 }
 
@@ -86,14 +82,119 @@ void reset_cache(pfhip_stream* s) {
   s->n_splice = 0;
 }
 
+// The front-end work of one batched call, recorded per connection while its host control flow runs and flushed as a
+// handful of batched launches (one per phase) instead of ~8 tiny launches per connection.  Operations of one connection
+// keep their order because the phases are flushed in program order; operations of different connections are independent.
+struct Recorder {
+  enum { kFramesToFb = 0, kFreshReplicate, kSpliceRotate, kWindow, kFeatc, kZeroPad, kPack, kCopyPhases };
+  std::vector<pfhip::RowsCopyOp> copies[kCopyPhases];
+  std::vector<pfhip::StreamLfrOp> lfr;
+  // fbank batch: PCM of every connection that has new frames, back to back
+  std::vector<const float*> pcm_src;
+  std::vector<int> pcm_len, nframes;
+  struct FrameDst { float* dst; int n; };
+  std::vector<FrameDst> frame_dst;
+  bool empty() const {
+    if (!lfr.empty() || !pcm_src.empty()) return false;
+    for (const auto& c : copies) if (!c.empty()) return false;
+    return true;
+  }
+  void copy(int phase, float* dst, int ldd, const float* src, int lds_, int nrows, int ncols) {
+    if (nrows > 0) copies[phase].push_back(pfhip::RowsCopyOp{dst, src, ldd, lds_, nrows, ncols});
+  }
+};
+
+pfhip_status flush(pfhip_model* m, Recorder& r, hipStream_t st) {
+  if (r.empty()) return PFHIP_OK;
+  const Config& c = m->cfg;
+  // ---- fbank of all new audio in one launch: PCM staged back to back, frames into a batch buffer -----------------
+  const int U = (int)r.pcm_src.size();
+  size_t total_samples = 0;
+  int total_frames = 0;
+  for (int u = 0; u < U; ++u) { total_samples += (size_t)r.pcm_len[u]; total_frames += r.nframes[u]; }
+  size_t n_ops = r.lfr.size();
+  for (const auto& cp : r.copies) n_ops += cp.size();
+  n_ops += (size_t)U;                                      // frames -> fb copies are appended below
+  const size_t meta_bytes = ((size_t)U * 8 + (size_t)(U + 1) * 4 + (size_t)U * 4 + 63) & ~(size_t)63;
+  const size_t ops_bytes = n_ops * sizeof(pfhip::RowsCopyOp) + 64;
+  const size_t pin_bytes = meta_bytes + ops_bytes + total_samples * 4 + 256;
+  if (pin_bytes > m->h_ops_cap) {
+    if (m->h_ops) HIP_TRY(hipHostFree(m->h_ops));
+    m->h_ops = nullptr; m->h_ops_cap = 0;
+    HIP_TRY(hipHostMalloc(&m->h_ops, pin_bytes * 2, hipHostMallocDefault));
+    m->h_ops_cap = pin_bytes * 2;
+  }
+  HIP_TRY(m->d_ops.ensure(meta_bytes + ops_bytes));
+  char* hp = static_cast<char*>(m->h_ops);
+  char* dp = static_cast<char*>(m->d_ops.p);
+  if (U > 0) {
+    HIP_TRY(m->pcm.ensure((total_samples + 1024) * 4));
+    HIP_TRY(m->fbk.ensure((size_t)total_frames * 80 * 4));
+    int64_t* h_soff = reinterpret_cast<int64_t*>(hp);
+    int* h_foff = reinterpret_cast<int*>(hp + (size_t)U * 8);
+    int* h_nf = h_foff + (U + 1);
+    float* h_pcm = reinterpret_cast<float*>(hp + meta_bytes + ops_bytes);
+    size_t so = 0; int fo = 0;
+    for (int u = 0; u < U; ++u) {
+      h_soff[u] = (int64_t)so; h_foff[u] = fo; h_nf[u] = r.nframes[u];
+      std::memcpy(h_pcm + so, r.pcm_src[u], (size_t)r.pcm_len[u] * 4);
+      r.copy(Recorder::kFramesToFb, r.frame_dst[u].dst, 80, m->fbk.f() + (size_t)fo * 80, 80, r.frame_dst[u].n, 80);
+      so += (size_t)r.pcm_len[u]; fo += r.nframes[u];
+    }
+    h_foff[U] = fo;
+    HIP_TRY(hipMemcpyAsync(m->pcm.p, h_pcm, total_samples * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dp, hp, meta_bytes, hipMemcpyHostToDevice, st));
+    pfhip::FbankTables tb{m->d_window, m->d_tw, m->d_mel_off, m->d_mel_size, m->d_mel_w, m->W("cmvn.mean").d, m->W("cmvn.istd").d};
+    pfhip::launch_fbank_frames_batch(m->pcm.f(), reinterpret_cast<const int64_t*>(dp), reinterpret_cast<const int*>(dp + (size_t)U * 8),
+                                     reinterpret_cast<const int*>(dp + (size_t)U * 8 + (size_t)(U + 1) * 4), U, total_frames, tb,
+                                     m->fbk.f(), st);
+  }
+  // ---- descriptor arrays: one upload, then the phases in program order ----------------------------------------------
+  char* h_ops = hp + meta_bytes;
+  char* d_ops = dp + meta_bytes;
+  size_t off = 0;
+  size_t phase_off[Recorder::kCopyPhases];
+  for (int ph = 0; ph < Recorder::kCopyPhases; ++ph) {
+    phase_off[ph] = off;
+    const size_t nb = r.copies[ph].size() * sizeof(pfhip::RowsCopyOp);
+    if (nb) std::memcpy(h_ops + off, r.copies[ph].data(), nb);
+    off += nb;
+  }
+  const size_t lfr_off = off;
+  if (!r.lfr.empty()) std::memcpy(h_ops + off, r.lfr.data(), r.lfr.size() * sizeof(pfhip::StreamLfrOp));
+  off += r.lfr.size() * sizeof(pfhip::StreamLfrOp);
+  if (off) HIP_TRY(hipMemcpyAsync(d_ops, h_ops, off, hipMemcpyHostToDevice, st));
+  auto run_copies = [&](int ph) {
+    int mx = 0;
+    for (const auto& o : r.copies[ph]) mx = std::max(mx, o.nrows);
+    pfhip::launch_rows_copy_batch(reinterpret_cast<const pfhip::RowsCopyOp*>(d_ops + phase_off[ph]), (int)r.copies[ph].size(), mx, st);
+  };
+  run_copies(Recorder::kFramesToFb);
+  run_copies(Recorder::kFreshReplicate);
+  {
+    int mx = 0;
+    for (const auto& o : r.lfr) mx = std::max(mx, o.n_rows);
+    pfhip::launch_stream_lfr_batch(reinterpret_cast<const pfhip::StreamLfrOp*>(d_ops + lfr_off), (int)r.lfr.size(), mx,
+                                   m->W("cmvn.mean").d, m->W("cmvn.istd").d, sqrtf((float)c.d_model), m->d_inv_ts, m->feat_dim, st);
+  }
+  run_copies(Recorder::kSpliceRotate);
+  run_copies(Recorder::kWindow);
+  run_copies(Recorder::kFeatc);
+  run_copies(Recorder::kZeroPad);
+  run_copies(Recorder::kPack);
+  HIP_TRY(hipGetLastError());
+  r = Recorder();
+  return PFHIP_OK;
+}
+
 // ForwardChunk (:415-523) for every stream in `ss` at once: stream b's window (win_n rows) is waiting in its `chunk`
 // buffer.  Appends each stream's ids to outs[b].
 pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& ss, hipStream_t st,
-                             const std::vector<std::vector<int32_t>*>& outs, bool want_logp) {
+                             const std::vector<std::vector<int32_t>*>& outs, bool want_logp, Recorder& rec) {
   const Config& c = m->cfg;
   const int d = c.d_model, FD = m->feat_dim, FP = m->feat_pad, B = (int)ss.size();
   const float att_scale = 1.0f / sqrtf((float)pfhip::kHeadDim);
-  if (B == 0) return PFHIP_OK;
+  if (B == 0) return flush(m, rec, st);
   std::vector<pfhip::StreamSeg> segs(B);
   int M = 0;
   for (int b = 0; b < B; ++b) {
@@ -144,9 +245,13 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   HIP_TRY(hipMemcpyAsync(dm, hm, (4 * (size_t)B + 2 * (size_t)M) * 4, hipMemcpyHostToDevice, st));
   pfhip::StreamSeg* d_segs = static_cast<pfhip::StreamSeg*>(m->sseg.p);
   HIP_TRY(hipMemcpyAsync(d_segs, h_segs, (size_t)B * sizeof(pfhip::StreamSeg), hipMemcpyHostToDevice, st));
-  // pack the windows
+  // pack the windows (one batched copy; also flushes whatever front-end work the callers recorded)
   for (int b = 0; b < B; ++b)
-    pfhip::launch_rows_copy(m->x0.f() + (size_t)segs[b].row_off * FP, FP, ss[b]->chunk.f(), FP, segs[b].n, FP, st);
+    rec.copy(Recorder::kPack, m->x0.f() + (size_t)segs[b].row_off * FP, FP, ss[b]->chunk.f(), FP, segs[b].n, FP);
+  {
+    pfhip_status fs = flush(m, rec, st);
+    if (fs) return fs;
+  }
   int maxn = 0;
   for (int b = 0; b < B; ++b) maxn = std::max(maxn, segs[b].n);
   float* x = m->x.f();
@@ -265,14 +370,14 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
 }
 
 // window = feats_cache_ ++ rows[r0, r0+nr) (AddOverlapChunk :397-413); returns the window length in *n_out
-pfhip_status add_overlap_chunk(pfhip_stream* s, int r0, int nr, bool input_finished, hipStream_t st, int* n_out) {
+pfhip_status add_overlap_chunk(pfhip_stream* s, int r0, int nr, bool input_finished, Recorder& rec, int* n_out) {
   pfhip_model* m = s->m;
   const int FD = m->feat_dim, FP = m->feat_pad;
   const int nc = s->n_featc;
   int n = nc + nr;
   if (n > 128) return fail(PFHIP_ERR_ARG, "stream window too long");
-  pfhip::launch_rows_copy(s->chunk.f(), FP, s->featc.f(), FD, nc, FD, st);
-  pfhip::launch_rows_copy(s->chunk.f() + (size_t)nc * FP, FP, s->rows.f() + (size_t)r0 * FD, FD, nr, FD, st);
+  rec.copy(Recorder::kWindow, s->chunk.f(), FP, s->featc.f(), FD, nc, FD);
+  rec.copy(Recorder::kWindow, s->chunk.f() + (size_t)nc * FP, FP, s->rows.f() + (size_t)r0 * FD, FD, nr, FD);
   int keep;
   if (input_finished) {
     keep = s->chunk_size[0];
@@ -281,12 +386,12 @@ pfhip_status add_overlap_chunk(pfhip_stream* s, int r0, int nr, bool input_finis
   }
   if (keep > n) return fail(PFHIP_ERR_ARG, "stream window shorter than the look-back cache");
   // new feats_cache_ = last `keep` rows of the (unpadded) window; chunk has stride FP, featc FD
-  pfhip::launch_rows_copy(s->featc.f(), FD, s->chunk.f() + (size_t)(n - keep) * FP, FP, keep, FD, st);
+  rec.copy(Recorder::kFeatc, s->featc.f(), FD, s->chunk.f() + (size_t)(n - keep) * FP, FP, keep, FD);
   s->n_featc = keep;
   if (input_finished && !s->is_last_chunk) {
     const int total = s->chunk_size[0] + s->chunk_size[1] + s->chunk_size[2];
     if (total > n) {                                          // zero rows up to 20 (:402-408)
-      pfhip::launch_rows_copy(s->chunk.f() + (size_t)n * FP, FP, nullptr, 0, total - n, 0, st);
+      rec.copy(Recorder::kZeroPad, s->chunk.f() + (size_t)n * FP, FP, nullptr, 0, total - n, 0);
       n = total;
     }
   }
@@ -296,7 +401,7 @@ pfhip_status add_overlap_chunk(pfhip_stream* s, int r0, int nr, bool input_finis
 
 // OnlineLfrCmvn (:196-238) over the T frames at the front of fb[cur]; emits n rows (CMVN, x sqrt(d), PE) into
 // s->rows and rotates the splice cache.
-pfhip_status online_lfr_cmvn(pfhip_stream* s, int T, bool input_finished, hipStream_t st, int* n_rows) {
+pfhip_status online_lfr_cmvn(pfhip_stream* s, int T, bool input_finished, Recorder& rec, int* n_rows) {
   pfhip_model* m = s->m;
   const int lfr_m = m->cfg.lfr_m, lfr_n = m->cfg.lfr_n;
   const int T_lrf = (int)std::ceil((T - (lfr_m - 1) / 2) / (float)lfr_n);
@@ -309,11 +414,10 @@ pfhip_status online_lfr_cmvn(pfhip_stream* s, int T, bool input_finished, hipStr
   splice = std::min(T - 1, splice * lfr_n);
   if (n_out > kMaxRows) return fail(PFHIP_ERR_ARG, "too many LFR rows in one streaming call");
   const float* fb = s->fb[s->fb_cur].f();
-  pfhip::launch_stream_lfr(fb, T, n_out, m->W("cmvn.mean").d, m->W("cmvn.istd").d, sqrtf((float)m->cfg.d_model),
-                           m->d_inv_ts, s->start_idx, s->rows.f(), m->feat_dim, st);
+  if (n_out > 0) rec.lfr.push_back(pfhip::StreamLfrOp{fb, s->rows.f(), T, n_out, s->start_idx, 0});
   s->start_idx += n_out;                                               // GetPosEmb :242-243
   const int keep = T - splice;                                         // lfr_splice_cache_ = frames[splice:] (:226-228)
-  pfhip::launch_rows_copy(s->fb[s->fb_cur ^ 1].f(), 80, fb + (size_t)splice * 80, 80, keep, 80, st);
+  rec.copy(Recorder::kSpliceRotate, s->fb[s->fb_cur ^ 1].f(), 80, fb + (size_t)splice * 80, 80, keep, 80);
   s->fb_cur ^= 1;
   s->n_splice = keep;
   *n_rows = n_out;
@@ -321,12 +425,13 @@ pfhip_status online_lfr_cmvn(pfhip_stream* s, int T, bool input_finished, hipStr
 }
 
 // ExtractFeats (:147-194) + x*sqrt(d) + GetPosEmb (:549-555): leaves `*n_rows` finished LFR rows in s->rows.
-pfhip_status extract_feats(pfhip_stream* s, const float* pcm, int len, bool input_finished, hipStream_t st, int* n_rows) {
+pfhip_status extract_feats(pfhip_stream* s, const float* pcm, int len, bool input_finished, Recorder& rec, int* n_rows) {
   pfhip_model* m = s->m;
   *n_rows = 0;
   const int fl = 400, fs = 160, lfr_m = m->cfg.lfr_m;
   // FbankKaldi (:119-145): prepend input_cache_, keep what follows the last frame shift for the next call
-  std::vector<float> waves(s->input_cache);
+  std::vector<float>& waves = s->waves;            // lives until the flush of this call has copied it
+  waves.assign(s->input_cache.begin(), s->input_cache.end());
   waves.insert(waves.end(), pcm, pcm + len);
   const int total = (int)waves.size();
   int frame_number = (total - fl) / fs + 1;
@@ -339,29 +444,17 @@ pfhip_status extract_feats(pfhip_stream* s, const float* pcm, int len, bool inpu
     const int base = fresh ? (lfr_m - 1) / 2 : s->n_splice;
     if (used > kMaxSamples + 1024 || base + frame_number > kMaxFrames)
       return fail(PFHIP_ERR_ARG, "too many samples in one streaming call");
-    // through this connection's pinned staging area: the copy is truly asynchronous and `waves` may die with this scope;
-    // the area is next written by this connection's next call, after the forward of this one has synchronised
-    float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(s->h_pin) + 4096);
-    std::memcpy(stage, waves.data(), (size_t)used * 4);
-    HIP_TRY(hipMemcpyAsync(s->pcm.p, stage, (size_t)used * 4, hipMemcpyHostToDevice, st));
     float* fb = s->fb[s->fb_cur].f();
-    {
-      int64_t* hm64 = reinterpret_cast<int64_t*>(s->h_pin + 768);
-      hm64[0] = 0;
-      int* hm = s->h_pin + 772;
-      hm[0] = 0; hm[1] = frame_number; hm[2] = frame_number;
-      HIP_TRY(hipMemcpyAsync(s->meta.i() + 8, s->h_pin + 768, 32, hipMemcpyHostToDevice, st));
-      pfhip::FbankTables tb{m->d_window, m->d_tw, m->d_mel_off, m->d_mel_size, m->d_mel_w, m->W("cmvn.mean").d,
-                            m->W("cmvn.istd").d};
-      pfhip::launch_fbank_frames(s->pcm.f(), reinterpret_cast<int64_t*>(s->meta.i() + 8), s->meta.i() + 12,
-                                 s->meta.i() + 14, frame_number, tb, fb + (size_t)base * 80, st);
-    }
+    rec.pcm_src.push_back(waves.data());
+    rec.pcm_len.push_back(used);
+    rec.nframes.push_back(frame_number);
+    rec.frame_dst.push_back(Recorder::FrameDst{fb + (size_t)base * 80, frame_number});
     if (fresh) {     // lfr_splice_cache_ = (lfr_m-1)/2 copies of the first frame (:155-158)
-      pfhip::launch_rows_copy(fb, 80, fb + (size_t)base * 80, 0, base, 80, st);
+      rec.copy(Recorder::kFreshReplicate, fb, 80, fb + (size_t)base * 80, 0, base, 80);
       s->n_splice = base;
     }
     if (frame_number + s->n_splice >= lfr_m) {
-      rc = online_lfr_cmvn(s, s->n_splice + frame_number, input_finished, st, n_rows);
+      rc = online_lfr_cmvn(s, s->n_splice + frame_number, input_finished, rec, n_rows);
     } else {
       // (:172-177) the splice cache just grows.  The reference leaves the raw 80-dim frames in wav_feats
       // here and feeds them on — a latent bug only reachable with < 55 ms of audio in a non-final call,
@@ -369,7 +462,7 @@ pfhip_status extract_feats(pfhip_stream* s, const float* pcm, int len, bool inpu
       s->n_splice += frame_number;
     }
   } else if (input_finished) {
-    if (s->n_splice > 0) rc = online_lfr_cmvn(s, s->n_splice, true, st, n_rows);   // (:179-189)
+    if (s->n_splice > 0) rc = online_lfr_cmvn(s, s->n_splice, true, rec, n_rows);   // (:179-189)
   }
   if (input_finished) reset_cache(s);                                              // (:191-193)
   return rc;
@@ -413,9 +506,8 @@ void pfhip_stream_destroy(pfhip_stream* s) {
     std::lock_guard<std::mutex> lk(s->m->mu);
     (void)hipSetDevice(s->m->device);
     (void)hipStreamSynchronize(s->m->own_stream);
-    for (Buf* b : {&s->pcm, &s->fb[0], &s->fb[1], &s->rows, &s->featc, &s->chunk, &s->carry, &s->dcache, &s->meta})
+    for (Buf* b : {&s->fb[0], &s->fb[1], &s->rows, &s->featc, &s->chunk, &s->carry, &s->dcache})
       b->release();
-    if (s->h_pin) (void)hipHostFree(s->h_pin);
   }
   delete s;
 }
@@ -451,20 +543,20 @@ struct Call {
 };
 
 // up to the first ForwardChunk
-pfhip_status prepare_first(Call& c, hipStream_t st) {
+pfhip_status prepare_first(Call& c, Recorder& rec) {
   pfhip_stream* s = c.s;
   pfhip_model* m = s->m;
   // (:532-540) a short final call after the first chunk: flush the look-back cache as the last chunk
   if (c.n_samples < 16 * 60 && c.fin && !s->is_first_chunk) {
     s->is_last_chunk = true;
     s->win_n = s->n_featc;
-    pfhip::launch_rows_copy(s->chunk.f(), m->feat_pad, s->featc.f(), m->feat_dim, s->win_n, m->feat_dim, st);
+    rec.copy(Recorder::kWindow, s->chunk.f(), m->feat_pad, s->featc.f(), m->feat_dim, s->win_n, m->feat_dim);
     c.has_window = true;
     c.reinit = true;
     return PFHIP_OK;
   }
   if (s->is_first_chunk) s->is_first_chunk = false;
-  pfhip_status rc = extract_feats(s, c.pcm, c.n_samples, c.fin, st, &c.nr);
+  pfhip_status rc = extract_feats(s, c.pcm, c.n_samples, c.fin, rec, &c.nr);
   if (rc) return rc;
   if (c.nr == 0) return PFHIP_OK;                                      // (:545-547)
   if (c.fin) {
@@ -472,24 +564,25 @@ pfhip_status prepare_first(Call& c, hipStream_t st) {
     else c.second = true;                                                           // (:560-579) first chunk + last chunk
     c.reinit = true;
   }
-  rc = add_overlap_chunk(s, 0, c.nr, c.fin, st, &s->win_n);
+  rc = add_overlap_chunk(s, 0, c.nr, c.fin, rec, &s->win_n);
   if (rc) return rc;
   c.has_window = true;
   return PFHIP_OK;
 }
 
 // (:566-579) the last-chunk window of a final call that did not fit one chunk
-pfhip_status prepare_second(Call& c, hipStream_t st) {
+pfhip_status prepare_second(Call& c, Recorder& rec) {
   pfhip_stream* s = c.s;
   s->is_last_chunk = true;
   const int k = c.nr + s->chunk_size[2] - s->chunk_size[1];
-  return add_overlap_chunk(s, c.nr - k, k, c.fin, st, &s->win_n);
+  return add_overlap_chunk(s, c.nr - k, k, c.fin, rec, &s->win_n);
 }
 
 pfhip_status forward_calls(pfhip_model* m, std::vector<Call>& calls, hipStream_t st) {
   bool want_logp = false;
+  Recorder rec;
   for (Call& c : calls) {
-    pfhip_status rc = prepare_first(c, st);
+    pfhip_status rc = prepare_first(c, rec);
     if (rc) return rc;
     want_logp = want_logp || c.s->debug;
   }
@@ -498,11 +591,11 @@ pfhip_status forward_calls(pfhip_model* m, std::vector<Call>& calls, hipStream_t
     std::vector<std::vector<int32_t>*> outs;
     for (Call& c : calls) {
       if (round == 0 ? !c.has_window : !c.second) continue;
-      if (round == 1) { pfhip_status rc = prepare_second(c, st); if (rc) return rc; }
+      if (round == 1) { pfhip_status rc = prepare_second(c, rec); if (rc) return rc; }
       ss.push_back(c.s);
       outs.push_back(&c.out);
     }
-    pfhip_status rc = forward_windows(m, ss, st, outs, want_logp);
+    pfhip_status rc = forward_windows(m, ss, st, outs, want_logp, rec);
     if (rc) return rc;
   }
   pfhip_status rc = PFHIP_OK;

@@ -45,6 +45,37 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(float* __restrict__ dst,
 
 // One block per connection of the batch (blockIdx.x): the window of stream b is rows [row_off, row_off + n) of the packed
 // encoder output, its fires go to emb_all[b * emb_rows ...], its carry lives in the stream's own buffer.
+// Batched forms for many connections: blockIdx.y = operation, each with its own pointers (descriptor array in HBM).
+__global__ __launch_bounds__(192) void stream_lfr_batch_kernel(const StreamLfrOp* __restrict__ ops, const float* __restrict__ mean,
+                                                               const float* __restrict__ istd, float scale,
+                                                               const float* __restrict__ inv_ts, int ldo) {
+  const StreamLfrOp op = ops[blockIdx.y];
+  const int i = blockIdx.x;
+  if (i >= op.n_rows) return;
+  const float pos = (float)(op.pos0 + i + 1);
+  for (int c = threadIdx.x; c < kFeat; c += blockDim.x) {
+    const int j = c / kMels, bin = c - j * kMels;
+    int f = i * kLfrN + j;
+    if (f > op.T - 1) f = op.T - 1;
+    float x = op.fb[(size_t)f * kMels + bin];
+    x = (x + mean[c]) * istd[c];
+    x = x * scale;
+    const int half = kFeat / 2;
+    const int k = c < half ? c : c - half;
+    const float coe = inv_ts[k] * pos;
+    x = x + (c < half ? sinf(coe) : cosf(coe));
+    op.out[(size_t)i * ldo + c] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_copy_batch_kernel(const RowsCopyOp* __restrict__ ops) {
+  const RowsCopyOp op = ops[blockIdx.y];
+  const int r = blockIdx.x;
+  if (r >= op.nrows) return;
+  for (int c = threadIdx.x; c < op.ldd; c += blockDim.x)
+    op.dst[(size_t)r * op.ldd + c] = (op.src && c < op.ncols) ? op.src[(size_t)r * op.lds + c] : 0.f;
+}
+
 template <int NC>
 __global__ __launch_bounds__(512) void cif_stream_kernel(const float* __restrict__ enc_all, int lde,
                                                          const float* __restrict__ alphas_all,
@@ -169,6 +200,17 @@ void launch_stream_lfr(const float* fb, int T, int n_rows, const float* mean, co
 void launch_rows_copy(float* dst, int ldd, const float* src, int lds_, int nrows, int ncols, hipStream_t s) {
   if (nrows <= 0) return;
   hipLaunchKernelGGL(rows_copy_kernel, dim3(nrows), dim3(256), 0, s, dst, ldd, src, lds_, nrows, ncols);
+}
+
+void launch_stream_lfr_batch(const StreamLfrOp* ops, int n_ops, int max_rows, const float* mean, const float* istd, float scale,
+                             const float* inv_ts, int ldo, hipStream_t s) {
+  if (n_ops <= 0 || max_rows <= 0) return;
+  hipLaunchKernelGGL(stream_lfr_batch_kernel, dim3(max_rows, n_ops), dim3(192), 0, s, ops, mean, istd, scale, inv_ts, ldo);
+}
+
+void launch_rows_copy_batch(const RowsCopyOp* ops, int n_ops, int max_rows, hipStream_t s) {
+  if (n_ops <= 0 || max_rows <= 0) return;
+  hipLaunchKernelGGL(rows_copy_batch_kernel, dim3(max_rows, n_ops), dim3(256), 0, s, ops);
 }
 
 void launch_cif_stream(const float* enc, int lde, const float* alphas, const StreamSeg* segs, int B, float threshold, float tail,

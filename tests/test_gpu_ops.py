@@ -182,3 +182,25 @@ def test_logsoftmax_argmax_first_max_wins(ops):
     z = x[:, :V] - x[:, :V].max(-1, keepdims=True)
     ref = z - np.log(np.exp(z).sum(-1, keepdims=True))
     assert np.abs(logp - ref).max() < 1e-5
+
+
+def test_gemm_random_shapes_all_kernels(ops):
+    """Seeded random (M, N, K) incl. ragged edges, every kernel kind with bounds checks on: catches tile-edge mistakes that
+    the fixed shapes above might miss."""
+    rng = np.random.default_rng(123)
+    for trial in range(24):
+        M = int(rng.integers(1, 700))
+        N = int(rng.integers(1, 900))
+        K = 32 * int(rng.integers(1, 20))
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        R1 = rng.standard_normal((M, N)).astype(np.float32)
+        Np = (N + 127) // 128 * 128
+        dA, dW = dev(pad_rows(A)), dev(pad_rows(W))
+        dbias = dev(np.concatenate([bias, np.zeros(Np - N, np.float32)]))
+        dR1 = dev(np.pad(pad_rows(R1), ((0, 0), (0, Np - N))))
+        ref = np.maximum(A @ W.T + bias + R1, 0)
+        for kind in (1, 2, 3):
+            C = ops.gemm_f32(dA, dW, bias=dbias, R1=dR1, relu=True, M=M, N=N, guard=True, kind=kind).cpu().numpy()
+            assert np.abs(C[:M, :N] - ref).max() < 3e-5 * max(1.0, np.sqrt(K / 512)), (M, N, K, kind)

@@ -97,33 +97,33 @@ __global__ __launch_bounds__(128) void fsmn_kernel(const float* __restrict__ v, 
     for (int j = 0; j < kFsmnK; ++j) wk[ch][j] = w[(size_t)(c + ch) * kFsmnK + j];
 
   constexpr int kHalf = LPAD;
-  float4 win[kFsmnK];
-  auto load_row = [&](int t) -> float4 {
-    if (t < 0 || t >= L) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return *reinterpret_cast<const float4*>(v + (base + t) * ldv + c);
-  };
+  // all kTT + 10 input rows of this thread are requested up front (26 independent 16-byte loads in flight per lane; 8-row tiles with more blocks measured slower: the
+  // kernel is HBM-latency-bound with only 8 waves per CU), then the 11-tap sums run from registers
+  float4 rows[kTT + kFsmnK - 1];
 #pragma unroll
-  for (int j = 0; j < kFsmnK - 1; ++j) win[j + 1] = load_row(t0 - kHalf + j);
+  for (int j = 0; j < kTT + kFsmnK - 1; ++j) {
+    const int t = t0 - kHalf + j;
+    rows[j] = (t < 0 || t >= L) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(v + (base + t) * ldv + c);
+  }
+  float4 rr[kTT];
+  if (res) {
+#pragma unroll
+    for (int s = 0; s < kTT; ++s)
+      rr[s] = (t0 + s < L) ? *reinterpret_cast<const float4*>(res + (base + t0 + s) * ldres + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int s = 0; s < kTT; ++s) {
     const int t = t0 + s;
-    // slide: win[j] <- win[j+1]; newest row enters at the end
-#pragma unroll
-    for (int j = 0; j < kFsmnK - 1; ++j) win[j] = win[j + 1];
-    win[kFsmnK - 1] = load_row(t + kFsmnK - 1 - kHalf);
     if (t < L) {
-      float4 o = win[kHalf];
-      if (res) {
-        const float4 rr = *reinterpret_cast<const float4*>(res + (base + t) * ldres + c);
-        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-      }
+      float4 o = rows[s + kHalf];
+      if (res) { o.x += rr[s].x; o.y += rr[s].y; o.z += rr[s].z; o.w += rr[s].w; }
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < kFsmnK; ++j) {
-        a.x += wk[0][j] * win[j].x;
-        a.y += wk[1][j] * win[j].y;
-        a.z += wk[2][j] * win[j].z;
-        a.w += wk[3][j] * win[j].w;
+        a.x += wk[0][j] * rows[s + j].x;
+        a.y += wk[1][j] * rows[s + j].y;
+        a.z += wk[2][j] * rows[s + j].z;
+        a.w += wk[3][j] * rows[s + j].w;
       }
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       *reinterpret_cast<float4*>(out + (base + t) * ldo + c) = o;

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
     "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
-    "pfhip_timestamp_onnx",
+    "pfhip_timestamp_onnx", "pfhip_post_process",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
     "pfhip_punc_infer_online", "pfhip_punc_add_punc",
 ]

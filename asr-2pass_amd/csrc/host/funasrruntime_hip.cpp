@@ -171,13 +171,23 @@ FUNASR_RESULT FunOfflineInferBuffer(FUNASR_HANDLE handle, const char* sz_buf, in
     if (fn_callback) fn_callback(++step, (int)index_vector.size());
   }
   std::string cur_stamp = "[";
-  for (size_t idx = 0; idx < msgs.size(); ++idx) {
+  for (size_t idx = 0; idx < msgs.size(); ++idx) {                                     // funasrruntime.cpp:291-312
     if (msgs[idx].empty()) continue;
-    res->msg += msgs[idx];
-    const float t0 = (float)res->segs[idx].first / (float)sampling_rate;                        // msg_stimes
-    for (size_t i = 0; i + 2 < spans[idx].size() + 1 && i + 2 <= spans[idx].size(); i += 3) {      // (begin_s, end_s, is_sil)
-      if (spans[idx][i + 2] != 0.f) continue;                                                   // <sil> spans carry no character
-      cur_stamp += "[" + std::to_string((int)(1000 * (spans[idx][i] + t0))) + "," + std::to_string((int)(1000 * (spans[idx][i + 1] + t0))) + "],";
+    const float t0 = (float)res->segs[idx].first / (float)sampling_rate;               // msg_stimes
+    const size_t bar = msgs[idx].find(" | ");
+    res->msg += msgs[idx].substr(0, bar);
+    if (bar != std::string::npos) {                 // "<text> | b0, e0,b1, e1": seconds relative to the segment
+      std::vector<float> v;
+      std::stringstream ss(msgs[idx].substr(bar + 3));
+      std::string item;
+      while (std::getline(ss, item, ',')) { try { v.push_back(std::stof(item)); } catch (...) { break; } }
+      for (size_t i = 0; i + 1 < v.size(); i += 2)
+        cur_stamp += "[" + std::to_string((int)(1000 * (v[i] + t0))) + "," + std::to_string((int)(1000 * (v[i + 1] + t0))) + "],";
+    } else {                                        // no vocabulary loaded: ids as text, stamps straight from the adapter
+      for (size_t i = 0; i + 2 < spans[idx].size() + 1 && i + 2 <= spans[idx].size(); i += 3) {
+        if (spans[idx][i + 2] != 0.f) continue;
+        cur_stamp += "[" + std::to_string((int)(1000 * (spans[idx][i] + t0))) + "," + std::to_string((int)(1000 * (spans[idx][i + 1] + t0))) + "],";
+      }
     }
   }
   if (cur_stamp != "[") {

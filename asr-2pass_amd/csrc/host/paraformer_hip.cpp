@@ -1,5 +1,7 @@
 #include "paraformer_hip.h"
 
+#include "postprocess.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -129,6 +131,18 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
           pfhip_timestamp_onnx(usa.data() + (size_t)i * max_us, usp.data() + (size_t)i * max_us, usl[i], n_chars, 0.f, -1.5f,
                                spans.data(), (int)spans.size() / 3, &n_spans) == PFHIP_OK)
         tl_last_spans[i].assign(spans.begin(), spans.begin() + (size_t)3 * n_spans);
+      if (!tokens_.empty() && n_spans > 0) {
+        // time-stamp mode returns "<text> | <stamps>" (paraformer.cpp:398-406: Vector2String -> TimestampOnnx -> PostProcess)
+        std::vector<std::string> raw_char;
+        for (int id : tl_last_ids[i]) raw_char.push_back((size_t)id < tokens_.size() ? tokens_[id] : "<unk>");
+        std::vector<std::vector<float>> stamps;
+        for (int k = 0; k < n_spans; ++k)
+          if (spans[3 * k + 2] == 0.f) stamps.push_back({spans[3 * k], spans[3 * k + 1]});       // <sil> spans carry no character (util.cpp:957-961)
+        if ((int)stamps.size() >= n_chars) {
+          stamps.resize(raw_char.size(), {0.f, 0.f});          // the popped "</s>" is skipped before its stamp is read
+          results[i] = pfhip_host::PostProcess(raw_char, stamps);
+        }
+      }
     }
   }
   return results;

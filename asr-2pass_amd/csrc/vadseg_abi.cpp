@@ -3,6 +3,7 @@
 
 #include "../../include/pfhip.h"
 #include "host/timestamp.h"
+#include "host/postprocess.h"
 #include "host/vad_segmenter.h"
 #include "internal.h"
 
@@ -47,6 +48,18 @@ pfhip_status pfhip_timestamp_onnx(float* us_alphas, const float* us_cif_peak, in
   *n_spans = (int)r.size();
   if ((int)r.size() > cap_spans) return pfhip_detail::fail(PFHIP_ERR_CAPACITY, "span buffer too small");
   for (size_t i = 0; i < r.size(); ++i) { spans[3 * i] = r[i].begin_s; spans[3 * i + 1] = r[i].end_s; spans[3 * i + 2] = r[i].is_sil ? 1.f : 0.f; }
+  return PFHIP_OK;
+}
+
+pfhip_status pfhip_post_process(const char* const* chars, const float* stamps, int n, char* out, int cap, int* n_out) {
+  if ((n > 0 && (!chars || !stamps)) || n < 0 || !out || !n_out) return pfhip_detail::fail(PFHIP_ERR_ARG, "bad argument");
+  std::vector<std::string> rc(n);
+  std::vector<std::vector<float>> ts(n);
+  for (int i = 0; i < n; ++i) { rc[i] = chars[i] ? chars[i] : ""; ts[i] = {stamps[2 * i], stamps[2 * i + 1]}; }
+  const std::string r = pfhip_host::PostProcess(rc, ts);
+  *n_out = (int)r.size();
+  if ((int)r.size() + 1 > cap) return pfhip_detail::fail(PFHIP_ERR_CAPACITY, "output string buffer too small");
+  std::memcpy(out, r.c_str(), r.size() + 1);
   return PFHIP_OK;
 }
 

@@ -200,6 +200,10 @@ pfhip_status pfhip_vadseg_feed(pfhip_vadseg* s, const float* sil_prob, int n_fra
  * an inserted <sil>.  us_alphas is rescaled in place like the reference's by-reference argument. */
 pfhip_status pfhip_timestamp_onnx(float* us_alphas, const float* us_cif_peak, int n_frames3, int n_chars, float begin_time_ms,
                                   float total_offset, float* spans, int cap_spans, int* n_spans);
+/* `funasr::PostProcess` (onnxruntime/src/util.cpp:720-836), host string handling: n hypothesis tokens (vocabulary strings,
+ * UTF-8) + their (begin_s, end_s) stamps -> "<text> | <b0>, <e0>,<b1>, <e1>..." exactly as Paraformer::GreedySearch returns
+ * it in time-stamp mode; special tokens dropped, "@@" pieces merged, Latin words spaced.  *n_out = strlen (cap >= +1). */
+pfhip_status pfhip_post_process(const char* const* chars, const float* stamps, int n, char* out, int cap, int* n_out);
 
 /* ---- CT-Transformer punctuation forward ------------------------------------------------------------
  *   pfhip_punc_create_from_memory <-> CTTransformer::InitPunc session load (ct-transformer.cpp:14-37)

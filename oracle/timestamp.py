@@ -62,3 +62,56 @@ def timestamp_onnx(us_alphas, us_cif_peak, n_chars, begin_time=0.0, total_offset
             t[0] = F32(float(t[0]) + begin_time / 1000.0)
             t[1] = F32(float(t[1]) + begin_time / 1000.0)
     return [(float(a), float(b), bool(c)) for a, b, c in out]
+
+
+def _is_chinese(ch: str) -> bool:
+    b = ch.encode("utf-8")
+    if len(b) != 3:
+        return False
+    return 19968 <= ord(ch) <= 40959 if len(ch) == 1 else False
+
+
+def post_process(raw_char, stamps):
+    """funasr::PostProcess (util.cpp:720-836): hypothesis tokens + (begin, end) stamps -> "text | b0, e0,b1, e1"."""
+    merged, words = [], []
+    is_pre_english = is_combining = False
+    combine, begin = "", -1.0
+    n = len(raw_char)
+    for i, word in enumerate(raw_char):
+        if word in ("<s>", "</s>", "<unk>"):
+            continue
+        if "@@" in word:
+            if i == n - 1 or _is_chinese(raw_char[i + 1]):
+                word = word[:-2] + " "
+                if is_combining:
+                    combine += word
+                    is_combining = False
+                    word, combine = combine, ""
+            else:
+                combine += word[:-2]
+                if not is_combining:
+                    begin = stamps[i][0]
+                is_combining = True
+                continue
+        elif is_combining:
+            combine += word
+            is_combining = False
+            word, combine = combine, ""
+        if _is_chinese(word):
+            words.append(word)
+            merged.append([stamps[i][0], stamps[i][1]])
+            is_pre_english = False
+        else:
+            if is_pre_english:
+                words.append(" ")
+            words.append(word)
+            begin = stamps[i][0] if begin == -1.0 else begin
+            merged.append([begin, stamps[i][1]])
+            begin = -1.0
+            is_pre_english = True
+    stamp_str = ""
+    for i, (b, e) in enumerate(merged):
+        stamp_str += f"{float(np.float32(b)):.6f}, {float(np.float32(e)):.6f}"
+        if i != len(merged) - 1:
+            stamp_str += ","
+    return "".join(words) + " | " + stamp_str

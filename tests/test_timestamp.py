@@ -71,3 +71,48 @@ def test_random_against_oracle(pkg):
         idx = sorted(rng.choice(n, size=int(rng.integers(0, k + 3)), replace=False))
         p = peaks_at(n, idx)
         assert pkg.timestamp_onnx(a, p, k) == pytest.approx(T.timestamp_onnx(a, p, k), rel=1e-5, abs=1e-6)
+
+
+# ---- PostProcess (util.cpp:720-836): text + stamps assembly --------------------------------------------------------------
+def _post_process_abi(pkg, chars, stamps):
+    import ctypes
+    lib = pkg.load_lib()
+    n = len(chars)
+    arr = (ctypes.c_char_p * max(n, 1))(*[c.encode("utf-8") for c in chars])
+    st = np.ascontiguousarray(np.asarray(stamps, np.float32).reshape(-1))
+    out = ctypes.create_string_buffer(4096)
+    n_out = ctypes.c_int(0)
+    lib.pfhip_post_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    rc = lib.pfhip_post_process(arr, st.ctypes.data if n else None, n, out, 4096, ctypes.byref(n_out))
+    assert rc == 0
+    return out.value.decode("utf-8")
+
+
+def test_post_process_known_answers(pkg):
+    from oracle import timestamp as T
+    cases = [
+        # CJK characters: no spaces, one stamp each; special tokens dropped
+        (["<s>", "你", "好", "</s>"], [[0, 0.1], [0.1, 0.3], [0.3, 0.5], [0.5, 0.6]], "你好 | 0.100000, 0.300000,0.300000, 0.500000"),
+        # BPE pieces: "hel@@" + "lo" -> "hello", stamp from the first piece's begin to the last piece's end; words spaced
+        (["hel@@", "lo", "wor@@", "ld"], [[0.0, 0.2], [0.2, 0.4], [0.5, 0.7], [0.7, 1.0]], "hello world | 0.000000, 0.400000,0.500000, 1.000000"),
+        # Latin after CJK: no space in between; CJK after Latin resets the spacing
+        (["我", "love", "you", "们"], [[0, 1], [1, 2], [2, 3], [3, 4]], "我love you们 | 0.000000, 1.000000,1.000000, 2.000000,2.000000, 3.000000,3.000000, 4.000000"),
+        # a piece ending in "@@" right before a CJK character (or at the very end) is closed with a blank
+        (["lo@@", "中"], [[0, 1], [1, 2]], "lo 中 | 0.000000, 1.000000,1.000000, 2.000000"),
+        (["ab@@", "cd@@"], [[0, 1], [1, 2]], "abcd  | 0.000000, 2.000000"),
+        ([], [], " | "),
+    ]
+    for chars, stamps, want in cases:
+        assert T.post_process(chars, stamps) == want, chars
+        assert _post_process_abi(pkg, chars, stamps) == want, chars
+
+
+def test_post_process_random_agreement(pkg):
+    from oracle import timestamp as T
+    rng = np.random.default_rng(5)
+    vocab = ["你", "好", "世", "界", "a", "bc", "de@@", "f@@", "ghi", "<unk>", "</s>", "x@@", "é", "中"]
+    for _ in range(200):
+        n = int(rng.integers(0, 12))
+        chars = [vocab[int(k)] for k in rng.integers(0, len(vocab), n)]
+        t = np.cumsum(rng.uniform(0.01, 0.4, 2 * n)).astype(np.float32).reshape(n, 2) if n else np.zeros((0, 2), np.float32)
+        assert _post_process_abi(pkg, chars, t) == T.post_process(chars, t.tolist()), chars

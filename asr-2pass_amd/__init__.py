@@ -31,7 +31,8 @@ ABI_SYMBOLS = [
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
-    "pfhip_vad_forward_sil", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
+    "pfhip_vad_forward_sil", "pfhip_vad_stream_create", "pfhip_vad_stream_destroy", "pfhip_vad_stream_reset",
+    "pfhip_vad_stream_infer", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
     "pfhip_timestamp_onnx", "pfhip_post_process",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
     "pfhip_punc_infer_online", "pfhip_punc_add_punc",
@@ -109,6 +110,11 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_vad_num_classes.argtypes = [vp]
     lib.pfhip_vad_forward.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci)]
     lib.pfhip_vad_forward_sil.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci)]
+    lib.pfhip_vad_stream_create.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.pfhip_vad_stream_destroy.argtypes = [vp]
+    lib.pfhip_vad_stream_destroy.restype = None
+    lib.pfhip_vad_stream_reset.argtypes = [vp]
+    lib.pfhip_vad_stream_infer.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci), vp, ctypes.c_size_t, ctypes.POINTER(ci)]
     lib.pfhip_vadseg_create.argtypes = [ctypes.POINTER(vp)]
     lib.pfhip_vadseg_destroy.argtypes = [vp]
     lib.pfhip_vadseg_destroy.restype = None
@@ -522,6 +528,56 @@ class CTTransformerHip:
         else:
             _check(self._lib, self._lib.pfhip_punc_infer_online(self._h, ids.ctypes.data, n, int(nCacheSize), punc.ctypes.data, lp))
         return (punc, logits) if want_logits else punc
+
+
+class FsmnVadOnlineHip:
+    """`funasr::FsmnVadOnline` (onnxruntime/src/fsmn-vad-online.cpp): one per connection, built on an FsmnVadHip like
+    `FsmnVadOnline(FsmnVad*)`.  Infer(waves, input_finished) returns the (start_ms, end_ms) pairs of the online detector
+    (-1 = open), as `FsmnVadOnline::Infer` does; InferScores stops before the scorer (scores + the waveform it would get)."""
+
+    def __init__(self, vad: "FsmnVadHip", vad_silence_duration=800, vad_max_len=15000, vad_speech_noise_thres=0.8):
+        self._lib = load_lib()
+        self._vad = vad
+        self._h = ctypes.c_void_p()
+        _check(self._lib, self._lib.pfhip_vad_stream_create(vad._h, ctypes.byref(self._h)))
+        self._scorer = E2EVadModelHost()
+        self.vad_silence_duration_, self.vad_max_len_, self.vad_speech_noise_thres_ = vad_silence_duration, vad_max_len, vad_speech_noise_thres
+
+    def close(self):
+        if self._h:
+            self._lib.pfhip_vad_stream_destroy(self._h)
+            self._h = ctypes.c_void_p()
+            self._scorer.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def SetConfig(self, vad_tail_sil, vad_max_len):
+        self.vad_silence_duration_, self.vad_max_len_ = vad_tail_sil, vad_max_len
+
+    def InferScores(self, waves, input_finished=False):
+        x = np.ascontiguousarray(waves, dtype=np.float32)
+        cap = x.size // 160 + 16
+        sil = np.zeros(cap, np.float32)
+        wv = np.zeros(x.size + 2048, np.float32)
+        nf, nw = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_vad_stream_infer(self._h, x.ctypes.data if x.size else None, int(x.size),
+                                                           1 if input_finished else 0, sil.ctypes.data, cap, ctypes.byref(nf),
+                                                           wv.ctypes.data, wv.size, ctypes.byref(nw)))
+        return sil[:nf.value].copy(), wv[:nw.value].copy()
+
+    def Infer(self, waves, input_finished=False):
+        sil, wv = self.InferScores(waves, input_finished)
+        if sil.size == 0:
+            return []                                                          # fsmn-vad-online.cpp:140-146
+        return self._scorer(sil, wv, input_finished, True, self.vad_silence_duration_, self.vad_max_len_,
+                            self.vad_speech_noise_thres_, 16000)
+
+    def Reset(self):
+        _check(self._lib, self._lib.pfhip_vad_stream_reset(self._h))
 
 
 class E2EVadModelHost:

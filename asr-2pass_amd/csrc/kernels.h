@@ -166,6 +166,10 @@ void launch_fsmn_cached(const float* t2, const float* w, const float* res, float
 // Generic LfrCmvn over raw fbank frames fb [F, n_mels] -> out [T = ceil(F/n), ldo] (columns >= m*n_mels zeroed).
 void launch_lfr_cmvn(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,
                      float* out, int ldo, hipStream_t s);
+// OnlineLfrCmvn form (fsmn-vad-online.cpp:90-133): row i = frames [i*n, i*n + m) of fb (which starts with the splice cache),
+// the tail replicated with the last frame; no left padding.
+void launch_lfr_cmvn_online(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,
+                            float* out, int ldo, hipStream_t s);
 // Memory block with left order 20: out = p + causal depthwise conv over [cache(19 rows); p]; cache_out (may be
 // null) receives the last 19 rows of [cache_in; p] and must not alias cache_in.
 void launch_fsmn_causal20(const float* p, int ldp, const float* w, const float* cache_in, float* cache_out, float* out,

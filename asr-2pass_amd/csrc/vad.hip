@@ -10,13 +10,15 @@ namespace {
 
 // LfrCmvn (onnxruntime/src/fsmn-vad.cpp:198-238 == paraformer.cpp:421-461) for any (m, n): row i = frames
 // [i*n - (m-1)/2, ...) with the first / last frame replicated; out = (x + mean) * istd; pad columns zeroed.
+// lp = left padding in frames: (m-1)/2 for the offline routine; 0 for OnlineLfrCmvn (fsmn-vad-online.cpp:90-133), whose
+// caller keeps the (m-1)/2 history frames in front of fb itself (lfr_splice_cache_).
 __global__ __launch_bounds__(128) void lfr_cmvn_kernel(const float* __restrict__ fb, int F, int T, int m, int n,
                                                        int n_mels, const float* __restrict__ mean,
                                                        const float* __restrict__ istd, float* __restrict__ out,
-                                                       int ldo) {
+                                                       int ldo, int lp) {
   const int i = blockIdx.x;
   if (i >= T) return;
-  const int D = m * n_mels, lp = (m - 1) / 2;
+  const int D = m * n_mels;
   for (int c = threadIdx.x; c < ldo; c += blockDim.x) {
     float v = 0.f;
     if (c < D) {
@@ -104,7 +106,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 void launch_lfr_cmvn(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,
                      float* out, int ldo, hipStream_t s) {
   if (T <= 0) return;
-  hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(T), dim3(128), 0, s, fb, F, T, m, n, n_mels, mean, istd, out, ldo);
+  hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(T), dim3(128), 0, s, fb, F, T, m, n, n_mels, mean, istd, out, ldo, (m - 1) / 2);
+}
+
+void launch_lfr_cmvn_online(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,
+                            float* out, int ldo, hipStream_t s) {
+  if (T <= 0) return;
+  hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(T), dim3(128), 0, s, fb, F, T, m, n, n_mels, mean, istd, out, ldo, 0);
 }
 
 void launch_fsmn_causal20(const float* p, int ldp, const float* w, const float* cache_in, float* cache_out, float* out,

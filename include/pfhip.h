@@ -179,6 +179,22 @@ pfhip_status pfhip_vad_forward(pfhip_vad* v, const float* pcm, int n_samples, in
 pfhip_status pfhip_vad_forward_sil(pfhip_vad* v, const float* pcm, int n_samples, int is_final, float* sil_prob,
                                    size_t cap_floats, int* n_frames);
 
+/* ---- online FSMN-VAD: one pfhip_vad_stream per connection = one `funasr::FsmnVadOnline` --------------------------------
+ * (onnxruntime/src/fsmn-vad-online.cpp; built on the offline handle like FsmnVadOnline(FsmnVad*), :206-219).
+ *   pfhip_vad_stream_infer <-> FsmnVadOnline::Infer up to the scorer (:135-147): ExtractFeats with input_cache_ /
+ *                              lfr_splice_cache_ / reserve_waveforms_ (:11-88), OnlineLfrCmvn (:90-133), Forward with this
+ *                              connection's caches.  sil_prob receives the silence posterior of the *n_frames rows this call
+ *                              produced; waves_out the waveform FsmnVadOnline hands to vad_scorer for the same rows (:148) —
+ *                              feed both to pfhip_vadseg_feed(online = 1).  A final call is scored against zeroed caches and
+ *                              resets the object, as the reference does (Reset/ResetCache inside ExtractFeats, :84-87).
+ *   pfhip_vad_stream_reset <-> Reset + ResetCache (:160-163, fsmn-vad-online.h:59-63) */
+typedef struct pfhip_vad_stream pfhip_vad_stream;
+pfhip_status pfhip_vad_stream_create(pfhip_vad* v, pfhip_vad_stream** out);
+void pfhip_vad_stream_destroy(pfhip_vad_stream* vs);
+pfhip_status pfhip_vad_stream_reset(pfhip_vad_stream* vs);
+pfhip_status pfhip_vad_stream_infer(pfhip_vad_stream* vs, const float* pcm, int n_samples, int input_finished, float* sil_prob,
+                                    size_t cap_floats, int* n_frames, float* waves_out, size_t waves_cap, int* n_waves);
+
 /* ---- VAD end-point detector (host logic) -----------------------------------------------------------
  * `funasr::E2EVadModel` (onnxruntime/src/e2e-vad.h:268-783, WindowDetector :181-266, VADXOptions defaults :78-107)
  * restated on the host: sequential threshold / window logic over ~100 frames per second, no device work.

@@ -74,3 +74,108 @@ class FsmnVad:
         if not is_final:
             self.in_cache_ = caches
         return probs
+
+
+class FsmnVadOnline:
+    """FsmnVadOnline::Infer up to the score matrix + the waveform handed to the scorer (fsmn-vad-online.cpp:11-151):
+    FbankKaldi with input_cache_ (:11-38), ExtractFeats with lfr_splice_cache_ / reserve_waveforms_ (:40-88), OnlineLfrCmvn
+    (:90-133).  Infer returns (probs [n, n_out], waves) — `waves` is what vad_scorer receives for its dB computation (:148)."""
+
+    def __init__(self, W):
+        self.W = W
+        cfg = W.cfg
+        self.lfr_m, self.lfr_n = cfg["lfr_m"], cfg["lfr_n"]
+        self.fl, self.fs = 400, 160                      # 25 ms / 10 ms at 16 kHz (fsmn-vad-online.h:89-90)
+        self.InitCache()
+        self.ResetCache()
+
+    def InitCache(self):
+        cfg = self.W.cfg
+        self.in_cache_ = [np.zeros((cfg["lorder"] - 1, cfg["proj"]), F32) for _ in range(cfg["layers"])]
+
+    def ResetCache(self):
+        self.reserve_waveforms_ = np.zeros(0, F32)
+        self.input_cache_ = np.zeros(0, F32)
+        self.lfr_splice_cache_ = np.zeros((0, 80), F32)
+
+    def _fbank(self, waves):
+        """FbankKaldi (:11-38): returns (frames, waves trimmed to the samples the frames cover)."""
+        waves = np.concatenate([self.input_cache_, np.asarray(waves, F32)]).astype(F32)
+        n = len(waves)
+        frame_number = (n - self.fl) // self.fs + 1 if n >= self.fl else 0
+        self.input_cache_ = waves[frame_number * self.fs:].copy()
+        if frame_number == 0:
+            return np.zeros((0, 80), F32), waves
+        waves = waves[:(frame_number - 1) * self.fs + self.fl]
+        return fe.fbank(waves), waves
+
+    def _online_lfr_cmvn(self, feats, input_finished):
+        m, n = self.lfr_m, self.lfr_n
+        T = feats.shape[0]
+        T_lrf = int(np.ceil((T - (m - 1) // 2) / float(n)))
+        splice = T_lrf
+        out = []
+        for i in range(T_lrf):
+            if m <= T - i * n:
+                out.append(feats[i * n:i * n + m].reshape(-1))
+            elif input_finished:
+                pad = m - (T - i * n)
+                out.append(np.concatenate([feats[i * n:].reshape(-1)] + [feats[-1]] * pad))
+            else:
+                splice = i
+                break
+        splice = min(T - 1, splice * n)
+        self.lfr_splice_cache_ = feats[splice:].copy()
+        rows = np.stack(out).astype(F32) if out else np.zeros((0, 80 * m), F32)
+        rows = ((rows + self.W["cmvn.mean"][None, :]).astype(F32) * self.W["cmvn.istd"][None, :]).astype(F32)
+        return rows, splice
+
+    def ExtractFeats(self, waves, input_finished):
+        m = self.lfr_m
+        feats, waves = self._fbank(waves)
+        rows = np.zeros((0, 80 * m), F32)
+        if feats.shape[0] > 0:
+            if len(self.reserve_waveforms_):
+                waves = np.concatenate([self.reserve_waveforms_, waves]).astype(F32)
+            if self.lfr_splice_cache_.shape[0] == 0:
+                self.lfr_splice_cache_ = np.repeat(feats[:1], (m - 1) // 2, axis=0)
+            if feats.shape[0] + self.lfr_splice_cache_.shape[0] >= m:
+                feats = np.concatenate([self.lfr_splice_cache_, feats]).astype(F32)
+                frame_from_waves = (len(waves) - self.fl) // self.fs + 1
+                minus_frame = (m - 1) // 2 if len(self.reserve_waveforms_) == 0 else 0
+                rows, splice = self._online_lfr_cmvn(feats, input_finished)
+                reserve_frame_idx = abs(splice - minus_frame)
+                self.reserve_waveforms_ = waves[reserve_frame_idx * self.fs:frame_from_waves * self.fs].copy()
+                waves = waves[:(frame_from_waves - 1) * self.fs + self.fl]
+            else:
+                self.reserve_waveforms_ = waves[self.fl - self.fs:].copy()
+                self.lfr_splice_cache_ = np.concatenate([self.lfr_splice_cache_, feats]).astype(F32)
+                # the reference leaves the raw 80-dim frames in vad_feats here and runs the network on them (a latent
+                # bug, only reachable with < 4 frames in a call); no rows are produced in this restatement
+        else:
+            if input_finished:
+                if len(self.reserve_waveforms_):
+                    waves = self.reserve_waveforms_
+                feats = self.lfr_splice_cache_
+                if feats.shape[0] > 0:
+                    rows, _ = self._online_lfr_cmvn(feats, input_finished)
+        if input_finished:
+            self.InitCache_pending = True          # Reset() + ResetCache() happen after the forward below uses in_cache_
+            self.ResetCache()
+        return rows, waves
+
+    def Infer(self, waves, input_finished):
+        self.InitCache_pending = False
+        caches_before = self.in_cache_
+        rows, waves = self.ExtractFeats(waves, input_finished)
+        if self.InitCache_pending:
+            # the reference calls Reset() (fresh in_cache_) inside ExtractFeats, BEFORE Forward runs on this call's rows
+            # (:84-87 precede :143): the last call of a stream is scored against zeroed caches
+            self.InitCache()
+            caches_before = self.in_cache_
+        if rows.shape[0] == 0:
+            return np.zeros((0, self.W.cfg["n_out"]), F32), waves
+        probs, caches = forward(rows, self.W, caches_before)
+        if not input_finished:
+            self.in_cache_ = caches
+        return probs, waves

@@ -60,3 +60,37 @@ def test_final_call_does_not_advance_caches(vad):
     ref = V.FsmnVad(W).Forward(b, True)
     assert np.abs(got - ref).max() < TOL
     assert h.Forward(np.zeros(399, np.float32)).shape == (0, 248)      # no full window -> no scores (:245-247)
+
+
+def test_online_vad_matches_oracle_and_offline(pkg, weights_mod):
+    """FsmnVadOnline (per-connection feature caches + network caches) fed in 600-ms and in ragged steps: scores and the
+    waveform handed to the scorer equal the numpy restatement call by call; concatenated, the scores equal the one-pass
+    offline scores except for the final call (which the reference scores against zeroed caches)."""
+    man, blob = weights_mod.synth_vad_weights()
+    W = P.Weights(man, blob)
+    vad = pkg.FsmnVadHip().InitVad((man, blob))
+    rng = np.random.default_rng(12)
+    pcm = synth_pcm(3, 16000 * 4 + 1234, rng)
+    for steps in ([9600] * 7, [16000, 300, 50, 4000, 23000, 9600, 12000, 3000]):
+        cuts = np.cumsum([0] + steps)
+        cuts = [c for c in cuts if c < len(pcm)] + [len(pcm)]
+        on = pkg.FsmnVadOnlineHip(vad)
+        ref = V.FsmnVadOnline(W)
+        got_all = []
+        for j in range(len(cuts) - 1):
+            fin = j == len(cuts) - 2
+            chunk = pcm[cuts[j]:cuts[j + 1]]
+            sil, wv = on.InferScores(chunk, fin)
+            rp, rw = ref.Infer(chunk, fin)
+            assert sil.shape[0] == rp.shape[0], (j, sil.shape, rp.shape)
+            assert np.array_equal(wv, rw), j
+            if sil.size:
+                assert np.abs(sil - rp[:, 0]).max() < 2e-5, j
+            got_all.append(sil)
+        allp = np.concatenate(got_all)
+        off = vad.ForwardSil(pcm, is_final=True)
+        assert allp.shape == off.shape
+        last = len(got_all[-1])
+        assert np.abs(allp[:len(allp) - last] - off[:len(off) - last]).max() < 2e-5
+        on.close()
+    vad.close()

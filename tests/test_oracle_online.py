@@ -95,3 +95,32 @@ def test_fsmn_cached_is_causal_and_carries_state():
     a, c1 = PO.fsmn_cached(x[:7], w, cache)
     b, _ = PO.fsmn_cached(x[7:], w, c1)
     assert np.abs(np.concatenate([a, b]) - whole).max() < 1e-5
+
+
+def test_online_vad_restatement_equals_offline_scores():
+    """FsmnVadOnline restated (feature caches + network caches): fed in 600-ms steps it emits the same rows as the one-pass
+    offline forward, row for row, except the final call (scored against zeroed caches, fsmn-vad-online.cpp:84-87)."""
+    import importlib
+    import __graft_entry__ as ge
+    from conftest import synth_pcm
+    from oracle import fsmn_vad as V
+    from oracle import paraformer as P
+    wt = importlib.import_module(ge.load_package().__name__ + ".weights")
+    man, blob = wt.synth_vad_weights()
+    W = P.Weights(man, blob)
+    rng = np.random.default_rng(0)
+    pcm = synth_pcm(0, 16000 * 2 + 777, rng)
+    on = V.FsmnVadOnline(W)
+    outs, wave_lens = [], []
+    cuts = list(range(0, len(pcm), 9600)) + [len(pcm)]
+    for j in range(len(cuts) - 1):
+        p, w = on.Infer(pcm[cuts[j]:cuts[j + 1]], j == len(cuts) - 2)
+        outs.append(p)
+        wave_lens.append(len(w))
+        assert len(w) >= (400 + 160 * (len(p) - 1) if len(p) else 0)              # the scorer's waveform covers at least these rows
+    allp = np.concatenate(outs)
+    off = V.FsmnVad(W).Forward(pcm, True)
+    assert allp.shape == off.shape
+    last = len(outs[-1])
+    assert np.abs(allp[:-last] - off[:-last]).max() < 1e-6
+    assert len(on.input_cache_) == 0 and len(on.reserve_waveforms_) == 0      # reset by the final call

@@ -11,6 +11,7 @@
 #include <sstream>
 
 #include "paraformer_hip.h"
+#include "tpass_audio.h"
 
 namespace {
 
@@ -23,7 +24,7 @@ struct OfflineStreamHip {
 };
 
 struct RecogResult {               // funasr::FUNASR_RECOG_RESULT (com-define.h)
-  std::string msg, stamp;
+  std::string msg, stamp, tpass_msg;
   float snippet_time = 0.f;
   std::vector<std::vector<int>> seg_ids;
   std::vector<std::pair<int, int>> segs;
@@ -214,3 +215,161 @@ void FunASRFreeResult(FUNASR_RESULT result) { delete static_cast<RecogResult*>(r
 void FunOfflineUninit(FUNASR_HANDLE handle) { delete static_cast<OfflineStreamHip*>(handle); }
 const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->seg_ids; }
 const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->segs; }
+
+
+// ---- 2-pass --------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct TpassStreamHip {               // funasr::TpassStream (tpass-stream.cpp): the shared models
+  funasr::ParaformerHip asr, asr_online;
+  pfhip_vad* vad = nullptr;
+  float speech_noise_thres = 0.9f;
+  ~TpassStreamHip() { if (vad) pfhip_vad_destroy(vad); }
+};
+
+struct TpassOnlineStreamHip {         // funasr::TpassOnlineStream (tpass-online-stream.cpp:14-15): per connection
+  TpassStreamHip* shared = nullptr;
+  pfhip_stream* asr_online = nullptr;
+  pfhip_vad_stream* vad_online = nullptr;
+  pfhip_vadseg* scorer = nullptr;
+  pfhip_host::TpassAudio audio;
+  int chunk_len = 9600;
+  std::string online_res;
+  ~TpassOnlineStreamHip() {
+    if (asr_online) pfhip_stream_destroy(asr_online);
+    if (vad_online) pfhip_vad_stream_destroy(vad_online);
+    if (scorer) pfhip_vadseg_destroy(scorer);
+  }
+};
+
+pfhip_vad* LoadVad(const std::string& dir) {
+  std::vector<char> blob, man;
+  if (!ReadAll(dir + "/vad.pfhip.bin", blob) || !ReadAll(dir + "/vad.pfhip.json", man)) {
+    std::fprintf(stderr, "Error when load vad hip model: cannot read %s\n", dir.c_str());
+    std::exit(-1);
+  }
+  man.push_back('\0');
+  pfhip_vad* v = nullptr;
+  if (pfhip_vad_create_from_memory(blob.data(), blob.size(), man.data(), 0, &v) != PFHIP_OK) {
+    std::fprintf(stderr, "Error when load vad hip model: %s\n", pfhip_last_error());
+    std::exit(-1);
+  }
+  return v;
+}
+
+}  // namespace
+
+FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int thread_num) {
+  auto ts = std::make_unique<TpassStreamHip>();
+  auto init = [&](funasr::ParaformerHip& m, const std::string& dir) {
+    std::string tok = dir + "/tokens.json";
+    { std::ifstream probe(tok); if (!probe) tok.clear(); }
+    m.InitAsr(dir + "/model.pfhip.bin", "", dir + "/model.pfhip.json", tok, thread_num);
+  };
+  init(ts->asr, model_path[MODEL_DIR]);
+  init(ts->asr_online, model_path[ONLINE_MODEL_DIR]);
+  ts->vad = LoadVad(model_path[VAD_DIR]);
+  return ts.release();
+}
+
+FUNASR_HANDLE FunTpassOnlineInit(FUNASR_HANDLE tpass_handle, std::vector<int> chunk_size) {
+  TpassStreamHip* ts = static_cast<TpassStreamHip*>(tpass_handle);
+  if (!ts || chunk_size.size() != 3) return nullptr;
+  auto os = std::make_unique<TpassOnlineStreamHip>();
+  os->shared = ts;
+  if (pfhip_stream_create(ts->asr_online.Handle(), chunk_size.data(), &os->asr_online) != PFHIP_OK ||
+      pfhip_vad_stream_create(ts->vad, &os->vad_online) != PFHIP_OK || pfhip_vadseg_create(&os->scorer) != PFHIP_OK) {
+    std::fprintf(stderr, "FunTpassOnlineInit: %s\n", pfhip_last_error());
+    return nullptr;
+  }
+  // ParaformerOnline::chunk_len = chunk_size[1] * frame_shift(10 ms) * lfr_n(6) * 16 samples/ms (paraformer-online.cpp:40-43)
+  os->chunk_len = chunk_size[1] * 10 * 6 * 16;
+  return os.release();
+}
+
+FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_handle, const char* sz_buf, int n_len,
+                                  std::vector<std::vector<std::string>>& punc_cache, bool input_finished, int sampling_rate,
+                                  std::string wav_format, ASR_TYPE mode, const std::vector<std::vector<float>>& hw_emb, bool itn,
+                                  int vad_tail_sil, int vad_max_len, FUNASR_DEC_HANDLE dec_handle) {
+  (void)punc_cache; (void)itn; (void)dec_handle;
+  TpassStreamHip* ts = static_cast<TpassStreamHip*>(handle);
+  TpassOnlineStreamHip* os = static_cast<TpassOnlineStreamHip*>(online_handle);
+  if (!ts || !os || !sz_buf) return nullptr;
+  if (wav_format != "pcm" && wav_format != "PCM") return nullptr;                  // funasrruntime.cpp:523-531
+  if (sampling_rate != 16000) return nullptr;
+  if (!os->audio.LoadPcmwavOnline(sz_buf, n_len)) return nullptr;
+  auto res = std::make_unique<RecogResult>();
+  res->snippet_time = os->audio.GetTimeLen();
+  // FsmnVadOnline::Infer (fsmn-vad-online.cpp:135-151) as the VAD of Audio::Split
+  auto vad_infer = [&](std::vector<float>& waves, bool fin) -> std::vector<std::vector<int>> {
+    std::vector<float> sil(waves.size() / 160 + 16), wv(waves.size() + 4096);
+    int nf = 0, nw = 0;
+    if (pfhip_vad_stream_infer(os->vad_online, waves.data(), (int)waves.size(), fin ? 1 : 0, sil.data(), sil.size(), &nf, wv.data(),
+                               wv.size(), &nw) != PFHIP_OK) {
+      std::fprintf(stderr, "FunTpassInferBuffer: %s\n", pfhip_last_error());
+      return {};
+    }
+    if (nf == 0) return {};
+    std::vector<int32_t> pairs((size_t)2 * (nf + 8));
+    int n_seg = 0;
+    if (pfhip_vadseg_feed(os->scorer, sil.data(), nf, wv.data(), nw, fin ? 1 : 0, 1, vad_tail_sil, vad_max_len, ts->speech_noise_thres,
+                          16000, pairs.data(), (int)pairs.size() / 2, &n_seg) != PFHIP_OK)
+      return {};
+    std::vector<std::vector<int>> out;
+    for (int i = 0; i < n_seg; ++i) out.push_back({pairs[2 * i], pairs[2 * i + 1]});
+    return out;
+  };
+  os->audio.Split(vad_infer, os->chunk_len, input_finished, (pfhip_host::AsrType)mode);
+  pfhip_host::TpassFrame frame;
+  while (os->audio.FetchChunck(frame)) {                                            // funasrruntime.cpp:538-566
+    std::vector<int32_t> ids(256);
+    int n_ids = 0;
+    std::string msg;
+    if (pfhip_stream_forward(os->asr_online, frame.data.data(), (int)frame.data.size(), frame.is_final ? 1 : 0, ids.data(),
+                             (int)ids.size(), &n_ids) == PFHIP_OK)
+      msg = ts->asr_online.TokensToString(std::vector<int>(ids.begin(), ids.begin() + n_ids));
+    else
+      std::fprintf(stderr, "FunTpassInferBuffer: %s\n", pfhip_last_error());
+    if (mode == ASR_ONLINE) {
+      os->online_res += msg;
+      if (frame.is_final) { res->tpass_msg = os->online_res; os->online_res.clear(); }
+      res->msg += msg;
+    } else if (mode == ASR_TWO_PASS) {
+      res->msg += msg;
+    }
+  }
+  std::string cur_stamp = "[";
+  while (os->audio.FetchTpass(frame)) {                                             // funasrruntime.cpp:570-639
+    float* buff[1] = {frame.data.data()};
+    int len[1] = {(int)frame.data.size()};
+    const std::vector<std::string> msgs = ts->asr.Forward(buff, len, true, hw_emb, nullptr, 1);
+    std::string msg = msgs.empty() ? "" : msgs[0];
+    if (msg.empty()) continue;
+    const size_t bar = msg.find(" | ");
+    if (bar != std::string::npos) {
+      std::vector<float> v;
+      std::stringstream ss(msg.substr(bar + 3));
+      std::string item;
+      while (std::getline(ss, item, ',')) { try { v.push_back(std::stof(item)); } catch (...) { break; } }
+      for (size_t i = 0; i + 1 < v.size(); i += 2) {
+        const float b = v[i] + (float)frame.global_start / 1000.0f, e = v[i + 1] + (float)frame.global_start / 1000.0f;
+        cur_stamp += "[" + std::to_string((int)(1000 * b)) + "," + std::to_string((int)(1000 * e)) + "],";
+      }
+      msg = msg.substr(0, bar);
+    }
+    if (cur_stamp != "[") {
+      cur_stamp.erase(cur_stamp.size() - 1);
+      res->stamp += cur_stamp + "]";
+    }
+    res->tpass_msg = msg;
+  }
+  if (input_finished) os->audio.ResetIndex();
+  return res.release();
+}
+
+const char* FunASRGetTpassResult(FUNASR_RESULT result, int n_index) {
+  (void)n_index;
+  return result ? static_cast<RecogResult*>(result)->tpass_msg.c_str() : nullptr;
+}
+void FunTpassOnlineUninit(FUNASR_HANDLE online_handle) { delete static_cast<TpassOnlineStreamHip*>(online_handle); }
+void FunTpassUninit(FUNASR_HANDLE handle) { delete static_cast<TpassStreamHip*>(handle); }

@@ -21,6 +21,7 @@
 #define MODEL_DIR "model-dir"          // com-define.h:52-60 keys used by the offline path
 #define VAD_DIR "vad-dir"
 #define TOKEN_PATH "token-path"
+#define ONLINE_MODEL_DIR "online-model-dir"
 
 typedef void* FUNASR_HANDLE;
 typedef void* FUNASR_RESULT;
@@ -46,6 +47,23 @@ const char* FunASRGetStamp(FUNASR_RESULT result);
 float FunASRGetRetSnippetTime(FUNASR_RESULT result);
 void FunASRFreeResult(FUNASR_RESULT result);
 void FunOfflineUninit(FUNASR_HANDLE handle);
+
+// ---- 2-pass slice (funasrruntime.h:121-132; funasrruntime.cpp:52-63, 491-646, 816-842) ---------------------------------------
+//   FunTpassInit         TpassStream: offline model (MODEL_DIR) + online model (ONLINE_MODEL_DIR) + VAD (VAD_DIR), shared
+//   FunTpassOnlineInit   TpassOnlineStream: one per connection — ParaformerOnline stream, FsmnVadOnline, Audio
+//   FunTpassInferBuffer  LoadPcmwavOnline -> Split (online VAD) -> streaming Forward per chunk -> offline Forward per closed
+//                        segment; msg = text of this call's streaming chunks, tpass_msg = 2nd-pass text of a segment that
+//                        closed in this call (punctuation / ITN of the reference are text handling above the path)
+FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int thread_num);
+FUNASR_HANDLE FunTpassOnlineInit(FUNASR_HANDLE tpass_handle, std::vector<int> chunk_size = {5, 10, 5});
+FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_handle, const char* sz_buf, int n_len,
+                                  std::vector<std::vector<std::string>>& punc_cache, bool input_finished = true,
+                                  int sampling_rate = 16000, std::string wav_format = "pcm", ASR_TYPE mode = ASR_TWO_PASS,
+                                  const std::vector<std::vector<float>>& hw_emb = {{0.0f}}, bool itn = true, int vad_tail_sil = 800,
+                                  int vad_max_len = 60000, FUNASR_DEC_HANDLE dec_handle = nullptr);
+const char* FunASRGetTpassResult(FUNASR_RESULT result, int n_index);
+void FunTpassOnlineUninit(FUNASR_HANDLE online_handle);
+void FunTpassUninit(FUNASR_HANDLE handle);
 
 // Inspection for tests: token ids per VAD segment in time order and the segments (samples) of the last result.
 const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result);

@@ -79,6 +79,9 @@ class ParaformerHip : public ParaformerHipBase {
   // (paraformer.cpp:545-562 + util.cpp:838-963); empty for plain models
   const std::vector<std::vector<float>>& LastTimestamps() const;
   void SetDevice(int device) { device_ = device; }
+  // the C-ABI handle underneath (streams of the online model are created from it) and the vocabulary mapping
+  pfhip_model* Handle() const { return handle_; }
+  std::string TokensToString(const std::vector<int>& ids) const { return IdsToString(ids); }
 
  private:
   std::string IdsToString(const std::vector<int>& ids) const;

@@ -136,3 +136,69 @@ def test_cpp_handle_api_matches_python_flow(pkg, weights_mod, tmp_path):
         assert len(pairs) == sum(len(x) for x in ids)                                 # one [begin,end] ms pair per token
         assert all(b <= e for b, e in pairs) and pairs == sorted(pairs)
     vad.close(); asr.close(); seg.close()
+
+
+def test_cpp_2pass_api_matches_python_flow(pkg, weights_mod, tmp_path):
+    """FunTpassInit / FunTpassOnlineInit / FunTpassInferBuffer (C++ mirror, `tpass_infer` harness) on one connection fed in
+    600-ms pieces: per call the streaming text and the 2nd-pass text of segments that closed equal the same flow assembled
+    in Python from the oracle's Audio::Split restatement and the plug-ins (online VAD, streaming and offline Paraformer)."""
+    import os
+    import subprocess
+    from oracle import audio_split as A
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    rng = np.random.default_rng(21)
+    pcm = make_file(rng)[:16000 * 30]
+    s16 = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2")
+    vman, vblob = shape_vad_weights(*weights_mod.synth_vad_weights())
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=1, vocab=300)
+    aman, ablob = weights_mod.synth_weights(cfg, seed=31)
+    oman, oblob = weights_mod.synth_weights(cfg, seed=32)
+    dirs = {k: tmp_path / k for k in ("asr", "online", "vad")}
+    for d in dirs.values():
+        d.mkdir()
+    weights_mod.save(str(dirs["asr"] / "model.pfhip"), aman, ablob)
+    weights_mod.save(str(dirs["online"] / "model.pfhip"), oman, oblob)
+    weights_mod.save(str(dirs["vad"] / "vad.pfhip"), vman, vblob)
+    s16.tofile(tmp_path / "stream.pcm")
+    exe = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "tpass_infer")
+    out = subprocess.run([exe, str(dirs["asr"]), str(dirs["online"]), str(dirs["vad"]), str(tmp_path / "stream.pcm"), "9600", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [l.split(" | ") for l in out.stdout.splitlines() if l.startswith("call ")]
+    # ---- the same flow in Python -------------------------------------------------------------------------------------
+    vad = pkg.FsmnVadHip().InitVad((vman, vblob))
+    asr = pkg.ParaformerHip().InitAsr((aman, ablob))
+    asr_on_model = pkg.ParaformerHip().InitAsr((oman, oblob))
+    vad_on = pkg.FsmnVadOnlineHip(vad, 800, 60000, 0.9)
+    stream = pkg.ParaformerOnlineHip(asr_on_model)
+    audio = A.TpassAudio()
+    f32 = (s16.astype(np.float32) / 32768.0).astype(np.float32)
+    n_calls = 0
+    n_tpass = 0
+    for j, off in enumerate(range(0, len(f32), 9600)):
+        last = off + 9600 >= len(f32)
+        audio.LoadPcmwavOnline(f32[off:off + 9600])
+        audio.Split(lambda w, fin: vad_on.Infer(w, fin), 9600, last, A.ASR_TWO_PASS)
+        online_txt = ""
+        while True:
+            fr = audio.FetchChunck()
+            if fr is None:
+                break
+            online_txt += " ".join(str(i) for i in stream.Forward(fr["data"], input_finished=fr["is_final"]))
+        tpass_txt = ""
+        while True:
+            fr = audio.FetchTpass()
+            if fr is None:
+                break
+            tpass_txt = " ".join(str(int(i)) for i in asr.forward_ids([fr["data"]])["ids"][0])
+            n_tpass += 1
+        if last:
+            audio.ResetIndex()
+        assert got[j][0] == f"call {j}"
+        assert got[j][1] == "online " + online_txt, (j, got[j][1], online_txt)
+        assert got[j][2] == "tpass " + tpass_txt, (j, got[j][2], tpass_txt)
+        n_calls += 1
+    assert n_calls == len(got) and n_tpass >= 3                 # several segments closed and were re-decoded offline
+    for o in (vad_on, stream, vad, asr, asr_on_model):
+        o.close()

@@ -154,6 +154,7 @@ def main():
     # launches of a step costs ~6 % of the step, bracketing the 284 GEMMs ~1 %
     model.profile_enable(0 if args.no_profile else GEMM_ONLY_MASK)
     model.profile_read(reset=True)
+    # the driver's contract: exactly K steps bracketed by barrier + synchronize on both sides, MAX over ranks below
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -163,6 +164,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+        torch.cuda.synchronize()       # the NCCL/RCCL barrier is enqueued on the stream: wait for it too
     dt = time.perf_counter() - t0
     prof = model.profile_read(reset=True)
     model.profile_enable(0)

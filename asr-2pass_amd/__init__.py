@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
     "pfhip_set_batching", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
-    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch",
+    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch", "pfhip_set_stream_batching",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
     "pfhip_vad_forward_sil", "pfhip_vad_stream_create", "pfhip_vad_stream_destroy", "pfhip_vad_stream_reset",
@@ -101,6 +101,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_stream_reset.argtypes = [vp]
     lib.pfhip_stream_forward.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
     lib.pfhip_stream_forward_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
+    lib.pfhip_set_stream_batching.argtypes = [vp, ci, ci]
     lib.pfhip_stream_set_debug.argtypes = [vp, ci]
     lib.pfhip_stream_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.pfhip_vad_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
@@ -204,6 +205,10 @@ class ParaformerHip:
 
     def GetBatchSize(self):
         return self._batch_size
+
+    def set_stream_batching(self, wait_us, max_streams=128):
+        """Merge concurrent ParaformerOnlineHip.Forward callers (one thread per connection) into batched forwards."""
+        _check(self._lib, self._lib.pfhip_set_stream_batching(self._h, int(wait_us), int(max_streams)))
 
     def set_batching(self, wait_us, max_utterances=32):
         """Merge concurrent Forward callers into one packed device batch (pfhip_set_batching)."""

@@ -155,6 +155,12 @@ struct pfhip_model {
   std::deque<struct BatchReq*> queue;
   bool leader_active = false;
   int batch_wait_us = 0, batch_max_utts = 32;
+  // the same for streaming calls: concurrent pfhip_stream_forward callers (one thread per connection) are merged
+  std::mutex sq_mu;
+  std::condition_variable sq_cv;
+  std::deque<struct StreamReq*> squeue;
+  bool sq_leader_active = false;
+  int stream_wait_us = 0, stream_max = 128;
 
   // profiling
   int prof_mask = 0;             // bit c set -> launches of kernel class c are bracketed by events

@@ -152,6 +152,11 @@ pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_sampl
 pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm,
                                         const int* n_samples, const int* input_finished, int32_t* const* token_ids,
                                         const int* cap, int* n_tokens);
+/* Cross-connection batching behind the per-connection call: with wait_us > 0, concurrent pfhip_stream_forward callers on
+ * different streams of model m (the 2-pass server's one-strand-per-connection threads, websocket-server-2pass.cpp:266-297)
+ * are merged into one pfhip_stream_forward_batch of up to max_streams connections; the first caller waits at most wait_us.
+ * Results are identical to separate calls.  0 switches it off (default). */
+pfhip_status pfhip_set_stream_batching(pfhip_model* m, int wait_us, int max_streams);
 /* Inspection of the LAST encoder window of the last call: "chunk" [n,560], "enc" [n,d], "alphas" [n],
  * "emb" [fires,d], "logp" [fires,vocab] (log-probs are only kept after pfhip_stream_set_debug(s,1)).
  * set_debug bit 1 = keep log-probs.  The tensors are read from the model's packed workspace: valid until the next forward. */

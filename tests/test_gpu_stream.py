@@ -167,3 +167,40 @@ def test_batched_connections_equal_separate_calls(pkg, weights_mod):
     for s in streams:
         s.close()
     model.close()
+
+
+def test_threads_per_connection_are_merged(pkg, weights_mod):
+    """pfhip_set_stream_batching: one thread per connection, each calling the per-connection Forward (the 2-pass server's
+    shape); concurrent calls are merged into batched forwards and every connection still gets exactly its own ids."""
+    import threading
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=2, vocab=500)
+    man, blob = weights_mod.synth_weights(cfg, seed=23)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    rng = np.random.default_rng(9)
+    waves = [synth_pcm(i, 9600 * (4 + i % 3) + 111 * i, rng) for i in range(12)]
+
+    def feed(stream, w, out):
+        steps = list(range(0, len(w), 9600))
+        for j, a in enumerate(steps):
+            out += stream.Forward(w[a:a + 9600], input_finished=(j == len(steps) - 1))
+
+    alone = []
+    for w in waves:
+        s = pkg.ParaformerOnlineHip(model)
+        ids = []
+        feed(s, w, ids)
+        alone.append(ids)
+        s.close()
+    model.set_stream_batching(3000, 64)
+    streams = [pkg.ParaformerOnlineHip(model) for _ in waves]
+    got = [[] for _ in waves]
+    ths = [threading.Thread(target=feed, args=(streams[i], waves[i], got[i])) for i in range(len(waves))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert got == alone
+    model.set_stream_batching(0, 1)
+    for s in streams:
+        s.close()
+    model.close()

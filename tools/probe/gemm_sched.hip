@@ -108,11 +108,67 @@ KERNEL(A_nomem)
 KERNEL(A_nosw)
 #pragma pop_macro("SW")
 
+
+// ---- schedule M: LDS-DMA staging, unpadded 128-B rows with a source-side XOR swizzle ------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+#pragma push_macro("FR")
+#undef FR
+#define FR(reg, base, off, buf, kb, j) reg = *(const float4*)(base + (buf) * 4096 + ((off) + 32 * (j)) * 32 + 4 * ((2 * (kb) + h) ^ ((((off) + 32 * (j)) >> 1) & 7)))
+#define DMA(j, buf) do { if ((j) < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)(Asrc[(j)] + knext), (lds_ptr_t)(As + (buf) * 4096 + (wave * 4 + (j)) * 256), 16, 0, 0); \
+  else __builtin_amdgcn_global_load_lds((glb_ptr_t)(Wsrc[(j) - 4] + knext), (lds_ptr_t)(Bs + (buf) * 4096 + (wave * 4 + (j) - 4) * 256), 16, 0, 0); } while (0)
+#define VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__global__ __launch_bounds__(256, 2) void gemm_M(const float* __restrict__ A, const float* __restrict__ W, float* C,
+                                                 int lda, int ldw, int ldc, int nk, int tiles_n, int n_tiles) {
+  __shared__ __attribute__((aligned(1024))) float lds[128 * kCs];          // 4 x 4096 operand floats; the C tile reuses it
+  float* const As = lds; float* const Bs = lds + 2 * 4096;
+  int bid = blockIdx.x;
+  { const int q = n_tiles >> 3, rr = n_tiles & 7, xcd = bid & 7;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3); }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const float* Asrc[4]; const float* Wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    Asrc[j] = A + (size_t)(m0 + row) * lda + 4 * c;
+    Wsrc[j] = W + (size_t)(n0 + row) * ldw + 4 * c;
+  }
+  f32x16 acc00, acc01, acc10, acc11;
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+  { const int knext = 0;
+    DMA(0, 0); DMA(1, 0); DMA(2, 0); DMA(3, 0); DMA(4, 0); DMA(5, 0); DMA(6, 0); DMA(7, 0); }
+  VMWAIT();
+  __syncthreads();
+  const int a_off = wr * 64 + r, b_off = wc * 64 + r;
+  float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
+  FR(fa0, As, a_off, 0, 0, 0); FR(fa1, As, a_off, 0, 0, 1); FR(fb0, Bs, b_off, 0, 0, 0); FR(fb1, Bs, b_off, 0, 0, 1);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    { const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * 32; LOOP_BODY_M_0 }
+    { const int knext = (kt + 2 < nk ? kt + 2 : nk - 1) * 32; LOOP_BODY_M_1 }
+  }
+  if (kt < nk) { const int knext = (nk - 1) * 32; LOOP_BODY_M_0 }
+  __syncthreads();
+  float* const Cs = lds;
+  { float* cw = Cs + (wr * 64 + 4 * h) * kCs + wc * 64 + r;
+    for (int e = 0; e < 16; ++e) { const int ro = ((e & 3) + 8 * (e >> 2)) * kCs; cw[ro] = acc00[e]; cw[ro + 32] = acc01[e];
+      cw[ro + 32 * kCs] = acc10[e]; cw[ro + 32 * kCs + 32] = acc11[e]; } }
+  __syncthreads();
+  const int c4 = tid & 31, rsub = tid >> 5;
+  _Pragma("unroll 4") for (int pass = 0; pass < 16; ++pass) { const int row = pass * 8 + rsub;
+    *(float4*)(C + (size_t)(m0 + row) * ldc + n0 + 4 * c4) = *(const float4*)(Cs + row * kCs + 4 * c4); }
+}
+#pragma pop_macro("FR")
+
 typedef void (*kern_t)(const float*, const float*, float*, int, int, int, int, int, int);
-static kern_t kernels[] = {gemm_H, gemm_H, gemm_H, gemm_H, gemm_H, gemm_H};
-static int gws[] = {0, 0, 0, 0, 0, 0};
-static int delays[] = {0, 1, 2, 4, 6, 0};
-static const char* names[] = {"H", "d3us", "d7us", "d14us", "d20us", "H"};
+static kern_t kernels[] = {gemm_H, gemm_M, gemm_H, gemm_M};
+static int gws[] = {0, 0, 0, 0};
+static int delays[] = {0, 0, 0, 0};
+static const char* names[] = {"H", "M(dma)", "H", "M(dma)"};
 
 float run(kern_t k, const float* A, const float* W, float* C, int M, int N, int K, int iters) {
   const int tiles_n = N / 128, blocks = (M / 128) * tiles_n;
@@ -151,6 +207,11 @@ int main() {
         if (rep > 0) best[v] = fminf(best[v], t);
       }
     for (int v = 0; v < nv; ++v) printf("  %s %6.1f us %5.1f TF", names[v], best[v] * 1e3, fl / best[v] / 1e9);
+    { std::vector<float> r0((size_t)M * N), r1((size_t)M * N);      // results of variant 1 against variant 0
+      hipMemset(C, 0, r0.size() * 4); run(kernels[0], A, W, C, M, N, K, 1); hipMemcpy(r0.data(), C, r0.size() * 4, hipMemcpyDeviceToHost);
+      hipMemset(C, 0, r0.size() * 4); run(kernels[1], A, W, C, M, N, K, 1); hipMemcpy(r1.data(), C, r0.size() * 4, hipMemcpyDeviceToHost);
+      double md = 0; for (size_t i = 0; i < r0.size(); ++i) md = fmax(md, fabs((double)r0[i] - r1[i]));
+      printf("  | max diff v1-v0 %g", md); }
     printf("\n");
     hipFree(A); hipFree(W); hipFree(C);
   }

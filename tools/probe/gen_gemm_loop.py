@@ -71,12 +71,21 @@ sched("S", {0: merge(spread(G, range(0, 8)), spread(R(1), range(8, 12)), {13: ["
             2: merge(spread(R(3), range(0, 4)), {8: ["E2"]}, spread(W[:4], range(12, 16))),
             3: merge(spread(W[4:], range(0, 4)), spread(R(4), range(7, 11)))}, barrier=(3, 6), pf=2)
 
+# M: LDS-DMA staging (global_load_lds_dwordx4, no staging registers, no ds_write): 8 DMA instructions per wave and K-tile
+#    issued singly under k-block 0, `s_waitcnt vmcnt(0)` (VW) right before the barrier that publishes the tile
+sched("M", {0: merge(spread([f"D{j}" for j in range(8)], range(0, 8)), spread(R(1), range(8, 12))), 1: spread(R(2), range(0, 4)),
+            2: spread(R(3), range(0, 4)), 3: merge({5: ["VW"]}, spread(R(4), range(7, 11)))}, barrier=(3, 6), pf=1)
+
 REGS = [["ra0", "ra1", "ra2", "ra3", "rb0", "rb1", "rb2", "rb3"], ["sa0", "sa1", "sa2", "sa3", "sb0", "sb1", "sb2", "sb3"]]
 
 
 def emit_op(op, cur, lset, sset):
     if op[0] == "E":
         return f"EP{op[1]}();"
+    if op[0] == "D":
+        return f"DMA({op[1]}, {cur ^ 1});"
+    if op == "VW":
+        return "VMWAIT();"
     if op[0] == "G":
         j = int(op[1])
         base, ld = ("Ag", "lda") if j < 4 else ("Wg", "ldw")

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
     "pfhip_vad_forward_sil", "pfhip_vad_stream_create", "pfhip_vad_stream_destroy", "pfhip_vad_stream_reset",
-    "pfhip_vad_stream_infer", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
+    "pfhip_vad_stream_infer", "pfhip_vad_stream_infer_batch", "pfhip_set_vad_stream_batching", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
     "pfhip_timestamp_onnx", "pfhip_post_process",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
     "pfhip_punc_infer_online", "pfhip_punc_add_punc",
@@ -116,6 +116,8 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_vad_stream_destroy.restype = None
     lib.pfhip_vad_stream_reset.argtypes = [vp]
     lib.pfhip_vad_stream_infer.argtypes = [vp, vp, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ci), vp, ctypes.c_size_t, ctypes.POINTER(ci)]
+    lib.pfhip_vad_stream_infer_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.pfhip_set_vad_stream_batching.argtypes = [vp, ci, ci]
     lib.pfhip_vadseg_create.argtypes = [ctypes.POINTER(vp)]
     lib.pfhip_vadseg_destroy.argtypes = [vp]
     lib.pfhip_vadseg_destroy.restype = None
@@ -463,6 +465,10 @@ class FsmnVadHip:
     def InitCache(self):
         _check(self._lib, self._lib.pfhip_vad_reset(self._h))
 
+    def set_stream_batching(self, wait_us, max_streams):
+        """Merge concurrent FsmnVadOnlineHip.Infer callers (one thread per connection) into batched device passes."""
+        _check(self._lib, self._lib.pfhip_set_vad_stream_batching(self._h, int(wait_us), int(max_streams)))
+
     def ForwardSil(self, waves, is_final=False):
         """Frame-wise silence posterior only (what E2EVadModel reads)."""
         x = np.ascontiguousarray(waves, dtype=np.float32)
@@ -573,6 +579,27 @@ class FsmnVadOnlineHip:
                                                            1 if input_finished else 0, sil.ctypes.data, cap, ctypes.byref(nf),
                                                            wv.ctypes.data, wv.size, ctypes.byref(nw)))
         return sil[:nf.value].copy(), wv[:nw.value].copy()
+
+    @staticmethod
+    def InferScoresBatch(streams, waves, input_finished):
+        """InferScores of several connections (of one FsmnVadHip) as one device pass; returns [(sil, waveform), ...]."""
+        n = len(streams)
+        lib = streams[0]._lib
+        xs = [np.ascontiguousarray(w, dtype=np.float32) for w in waves]
+        sils = [np.zeros(x.size // 160 + 16, np.float32) for x in xs]
+        wvs = [np.zeros(x.size + 2048, np.float32) for x in xs]
+        P = ctypes.c_void_p * n
+        h = P(*[s._h.value for s in streams])
+        px = P(*[x.ctypes.data if x.size else None for x in xs])
+        ns = (ctypes.c_int * n)(*[int(x.size) for x in xs])
+        fin = (ctypes.c_int * n)(*[1 if f else 0 for f in input_finished])
+        ps = P(*[a.ctypes.data for a in sils])
+        caps = (ctypes.c_size_t * n)(*[a.size for a in sils])
+        pw = P(*[a.ctypes.data for a in wvs])
+        wcaps = (ctypes.c_size_t * n)(*[a.size for a in wvs])
+        nf, nw = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        _check(lib, lib.pfhip_vad_stream_infer_batch(h, n, px, ns, fin, ps, caps, nf, pw, wcaps, nw))
+        return [(sils[i][:nf[i]].copy(), wvs[i][:nw[i]].copy()) for i in range(n)]
 
     def Infer(self, waves, input_finished=False):
         sil, wv = self.InferScores(waves, input_finished)

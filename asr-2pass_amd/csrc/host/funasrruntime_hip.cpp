@@ -268,9 +268,12 @@ FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int t
   };
   init(ts->asr, model_path[MODEL_DIR]);
   init(ts->asr_online, model_path[ONLINE_MODEL_DIR]);
-  // one strand per connection in the server: merge their concurrent streaming chunks into batched forwards
-  if (thread_num > 1) pfhip_set_stream_batching(ts->asr_online.Handle(), 3000, 128);
   ts->vad = LoadVad(model_path[VAD_DIR]);
+  // one handler thread per connection in the server: merge their concurrent device calls into batched passes
+  if (thread_num > 1) {
+    pfhip_set_stream_batching(ts->asr_online.Handle(), 3000, 128);
+    if (ts->vad) pfhip_set_vad_stream_batching(ts->vad, 1000, 256);
+  }
   return ts.release();
 }
 

@@ -172,8 +172,14 @@ void launch_lfr_cmvn_online(const float* fb, int F, int T, int m, int n, int n_m
                             float* out, int ldo, hipStream_t s);
 // Memory block with left order 20: out = p + causal depthwise conv over [cache(19 rows); p]; cache_out (may be
 // null) receives the last 19 rows of [cache_in; p] and must not alias cache_in.
-void launch_fsmn_causal20(const float* p, int ldp, const float* w, const float* cache_in, float* cache_out, float* out,
-                          int ldo, int T, int C, hipStream_t s);
-void launch_softmax_rows(const float* x, int ldx, int M, int N, float* y, hipStream_t s);
+// One connection's share of a packed FSMN-VAD forward: rows [row_off, row_off + T), network caches [layers][19][C]
+// (cache_out == nullptr: do not advance, the final call of fsmn-vad.cpp:129-134).
+struct VadSeg { const float* cache_in; float* cache_out; int row_off, T; };
+struct VadLfrOp { const float* fb; int Tin, n_out, row_off, pad_; };
+void launch_fsmn_causal20(const float* p, int ldp, const float* w, const VadSeg* segs, int B, int max_T, int layer, float* out,
+                          int ldo, int C, hipStream_t s);
+void launch_lfr_cmvn_online_batch(const VadLfrOp* ops, int n_ops, int max_rows, int m, int n, int n_mels, const float* mean,
+                                  const float* istd, float* out, int ldo, hipStream_t s);
+void launch_softmax_rows(const float* x, int ldx, int M, int N, float* y, float* col0, hipStream_t s);
 
 }  // namespace pfhip

@@ -5,6 +5,9 @@
 // onnxruntime/src/audio.cpp:1183-1196); slice-wise calls give the same scores because the caches carry over.
 // Linear layers run on the same fp32 MFMA GEMM kernels as the ASR model; their odd widths (140, 250, 248) are
 // zero-padded once at load ([N up to 128][K up to 32]) so that pad outputs are exact zeros.
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 
 #include "internal.h"
@@ -22,11 +25,14 @@ struct pfhip_vad {
   Lin in1, in2, out1, out2;
   std::vector<Lin> blk_linear, blk_affine;
   std::vector<float*> fsmn_w;
-  Buf pcm, fb, feats, a, b, p, f, probs, meta, cache[2];
+  Buf pcm, fb, feats, a, b, p, f, probs, sil, meta, cache[2], segs, fbk, ops;
   int cache_cur = 0;
   int* h_pin = nullptr;
   // pinned staging for the online path's PCM (grown on demand); h_wave(n) returns a buffer of at least n floats
   float* h_wave_buf = nullptr; size_t h_wave_cap = 0;
+  // merging of concurrent pfhip_vad_stream_infer callers (pfhip_set_vad_stream_batching)
+  std::mutex q_mu; std::condition_variable q_cv; std::deque<struct VadReq*> queue; bool q_leader_active = false;
+  int q_wait_us = 0, q_max = 1;
   float* h_wave(size_t n) {
     if (n > h_wave_cap) {
       if (h_wave_buf) (void)hipHostFree(h_wave_buf);
@@ -136,7 +142,7 @@ void pfhip_vad_destroy(pfhip_vad* v) {
   if (!v) return;
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
-  for (Buf* b : {&v->pcm, &v->fb, &v->feats, &v->a, &v->b, &v->p, &v->f, &v->probs, &v->meta, &v->cache[0], &v->cache[1]}) b->release();
+  for (Buf* b : {&v->pcm, &v->fb, &v->feats, &v->a, &v->b, &v->p, &v->f, &v->probs, &v->meta, &v->cache[0], &v->cache[1], &v->segs, &v->fbk, &v->ops, &v->sil}) b->release();
   auto fl = [](Lin& l) { free_lin(l); };
   fl(v->in1); fl(v->in2); fl(v->out1); fl(v->out2);
   for (auto& l : v->blk_linear) fl(l);
@@ -163,19 +169,19 @@ pfhip_status pfhip_vad_reset(pfhip_vad* v) {
 
 int pfhip_vad_num_classes(const pfhip_vad* v) { return v ? v->n_out : 0; }
 
-// The FSMN-VAD network on the T rows waiting in v->feats (caller holds v->mu and has sized the workspace); scores in v->probs.
-static void vad_network(pfhip_vad* v, hipStream_t s, int T, const float* cin, float* cout) {
+// The FSMN-VAD network on the T packed rows waiting in v->feats (caller holds v->mu and has sized the workspace); scores in
+// v->probs.  d_segs: one VadSeg per connection (its rows and caches), max_T = longest segment.
+static void vad_network(pfhip_vad* v, hipStream_t s, int T, const pfhip::VadSeg* d_segs, int B, int max_T) {
   lin_gemm(s, v->in1, v->feats.f(), v->in1.Kp, v->a.f(), 256, T, false);
   lin_gemm(s, v->in2, v->a.f(), 256, v->b.f(), 256, T, true);
   for (int i = 0; i < v->layers; ++i) {
     lin_gemm(s, v->blk_linear[i], v->b.f(), 256, v->p.f(), 128, T, false);
-    pfhip::launch_fsmn_causal20(v->p.f(), 128, v->fsmn_w[i], cin + (size_t)i * 19 * v->proj,
-                                cout ? cout + (size_t)i * 19 * v->proj : nullptr, v->f.f(), 128, T, v->proj, s);
+    pfhip::launch_fsmn_causal20(v->p.f(), 128, v->fsmn_w[i], d_segs, B, max_T, i, v->f.f(), 128, v->proj, s);
     lin_gemm(s, v->blk_affine[i], v->f.f(), 128, v->b.f(), 256, T, true);
   }
   lin_gemm(s, v->out1, v->b.f(), 256, v->a.f(), 256, T, false);
   lin_gemm(s, v->out2, v->a.f(), 256, v->b.f(), 256, T, false);
-  pfhip::launch_softmax_rows(v->b.f(), 256, T, v->n_out, v->probs.f(), s);
+  pfhip::launch_softmax_rows(v->b.f(), 256, T, v->n_out, v->probs.f(), v->sil.f(), s);
 }
 
 static pfhip_status vad_workspace(pfhip_vad* v, int T) {
@@ -186,6 +192,7 @@ static pfhip_status vad_workspace(pfhip_vad* v, int T) {
   HIP_TRY(v->p.ensure((size_t)Tp * 128 * 4));
   HIP_TRY(v->f.ensure((size_t)Tp * 128 * 4));
   HIP_TRY(v->probs.ensure((size_t)T * v->n_out * 4));
+  HIP_TRY(v->sil.ensure((size_t)T * 4));
   if (v->in1.Np > 256 || v->in2.Np > 256 || v->out1.Np > 256 || v->out2.Np > 256 || v->proj > 128)
     return fail(PFHIP_ERR_UNSUPPORTED, "FSMN-VAD layer wider than the workspace");
   return PFHIP_OK;
@@ -225,6 +232,7 @@ static pfhip_status vad_forward_impl(pfhip_vad* v, const float* pcm, int n_sampl
   HIP_TRY(v->p.ensure((size_t)Tp * 128 * 4));
   HIP_TRY(v->f.ensure((size_t)Tp * 128 * 4));
   HIP_TRY(v->probs.ensure((size_t)T * v->n_out * 4));
+  HIP_TRY(v->sil.ensure((size_t)T * 4));
   if (v->in1.Np > 256 || v->in2.Np > 256 || v->out1.Np > 256 || v->out2.Np > 256 || v->proj > 128)
     return fail(PFHIP_ERR_UNSUPPORTED, "FSMN-VAD layer wider than the workspace");
   HIP_TRY(hipMemcpyAsync(v->pcm.p, pcm, (size_t)n_samples * 4, hipMemcpyHostToDevice, s));
@@ -240,14 +248,16 @@ static pfhip_status vad_forward_impl(pfhip_vad* v, const float* pcm, int n_sampl
                              v->fb.f(), s);
   pfhip::launch_lfr_cmvn(v->fb.f(), F, T, v->lfr_m, v->lfr_n, v->n_mels, v->d_mean, v->d_istd, v->feats.f(), v->in1.Kp, s);
   {
-    const float* cin = v->cache[v->cache_cur].f();
-    float* cout = v->cache[v->cache_cur ^ 1].f();
-    vad_network(v, s, T, cin, is_final ? nullptr : cout);
+    pfhip::VadSeg* hs = reinterpret_cast<pfhip::VadSeg*>(v->h_pin + 16);
+    *hs = pfhip::VadSeg{v->cache[v->cache_cur].f(), is_final ? nullptr : v->cache[v->cache_cur ^ 1].f(), 0, T};
+    HIP_TRY(v->segs.ensure(sizeof(pfhip::VadSeg)));
+    HIP_TRY(hipMemcpyAsync(v->segs.p, hs, sizeof(pfhip::VadSeg), hipMemcpyHostToDevice, s));
+    vad_network(v, s, T, static_cast<const pfhip::VadSeg*>(v->segs.p), 1, T);
   }
   if (!is_final) v->cache_cur ^= 1;                             // fsmn-vad.cpp:129-134: caches kept only if not final
   if (probs && !sil_only) HIP_TRY(hipMemcpyAsync(probs, v->probs.p, (size_t)T * v->n_out * 4, hipMemcpyDeviceToHost, s));
   if (probs && sil_only)        // column 0 of the [T, n_out] score matrix
-    HIP_TRY(hipMemcpy2DAsync(probs, 4, v->probs.p, (size_t)v->n_out * 4, 4, T, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(probs, v->sil.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   return PFHIP_OK;
@@ -320,114 +330,325 @@ pfhip_status pfhip_vad_stream_reset(pfhip_vad_stream* vs) {
   return PFHIP_OK;
 }
 
-pfhip_status pfhip_vad_stream_infer(pfhip_vad_stream* vs, const float* pcm, int n_samples, int input_finished, float* sil_prob,
-                                    size_t cap_floats, int* n_frames, float* waves_out, size_t waves_cap, int* n_waves) {
-  last_error().clear();
-  if (!vs || n_samples < 0 || (n_samples > 0 && !pcm) || !n_frames || !n_waves) return fail(PFHIP_ERR_ARG, "bad argument");
-  if (n_samples > kVadMaxSamples) return fail(PFHIP_ERR_ARG, "more than 64000 samples in one online VAD call");
+}  // extern "C"
+
+namespace {
+
+// One connection's share of a (batched) FsmnVadOnline::Infer: the host part of ExtractFeats runs first and leaves a plan,
+// the device work of all connections is then issued as a handful of batched launches.
+struct VadCall {
+  pfhip_vad_stream* vs; const float* pcm; int n_samples; bool fin;
+  float* sil_prob; size_t cap_floats; int* n_frames; float* waves_out; size_t waves_cap; int* n_waves;
+  // plan.  buf = this call's slice of the pinned sample staging: [reserve_waveforms_ | input_cache_ | new samples]
+  float* buf = nullptr;
+  size_t fb_off = 0, fb_len = 0;    // samples (relative to buf) whose frames are computed in this call
+  size_t out_off = 0, out_len = 0;  // what the scorer gets
+  size_t used = 0;
+  int frame_number = 0, base = 0, n_rows = 0, Tin = 0, splice = 0;
+  bool fresh = false, run_lfr = false;
+  int row_off = 0;
+};
+
+// ExtractFeats (:40-88) on counters and sample ranges only; the one copy of the samples made here is the one into the
+// staging buffer the device reads
+pfhip_status vad_plan(VadCall& c) {
+  pfhip_vad_stream* vs = c.vs;
   pfhip_vad* v = vs->v;
-  std::lock_guard<std::mutex> lk(v->mu);
-  HIP_TRY(hipSetDevice(v->device));
-  hipStream_t s = v->stream;
-  const bool fin = input_finished != 0;
   const int fl = 400, fs = 160, m = v->lfr_m, n = v->lfr_n;
-  *n_frames = 0; *n_waves = 0;
-  // ---- FbankKaldi (:11-38): prepend input_cache_, keep what follows the last frame shift ------------------------------
-  std::vector<float> waves(vs->input_cache);
-  waves.insert(waves.end(), pcm, pcm + n_samples);
-  const int total = (int)waves.size();
-  int frame_number = total >= fl ? (total - fl) / fs + 1 : 0;
-  vs->input_cache.assign(waves.begin() + (size_t)frame_number * fs, waves.end());
-  int n_rows = 0, T = 0;
-  float* fb = vs->fb[vs->fb_cur].f();
-  auto online_lfr = [&](int Tin) -> pfhip_status {          // OnlineLfrCmvn (:90-133) over the Tin frames at the front of fb
+  const size_t r0 = vs->reserve.size(), ic = vs->input_cache.size();
+  if (r0) std::memcpy(c.buf, vs->reserve.data(), r0 * 4);
+  if (ic) std::memcpy(c.buf + r0, vs->input_cache.data(), ic * 4);
+  if (c.n_samples) std::memcpy(c.buf + r0 + ic, c.pcm, (size_t)c.n_samples * 4);
+  c.used = r0 + ic + (size_t)c.n_samples;
+  const float* W = c.buf + r0;                              // `waves` = input_cache_ ++ new samples (:43-44)
+  const int total = (int)(ic + (size_t)c.n_samples);
+  c.frame_number = total >= fl ? (total - fl) / fs + 1 : 0;
+  vs->input_cache.assign(W + (size_t)c.frame_number * fs, W + total);
+  auto online_lfr = [&](int Tin) {                          // OnlineLfrCmvn (:90-133): counts only
     const int T_lrf = (int)std::ceil((Tin - (m - 1) / 2) / (float)n);
     int splice = T_lrf, n_out = 0;
     for (int i = 0; i < T_lrf; ++i) {
       if (m <= Tin - i * n) ++n_out;
-      else if (fin) ++n_out;
+      else if (c.fin) ++n_out;
       else { splice = i; break; }
     }
-    splice = std::min(Tin - 1, splice * n);
-    pfhip_status ws = vad_workspace(v, std::max(n_out, 1));
-    if (ws) return ws;
-    pfhip::launch_lfr_cmvn_online(fb, Tin, n_out, m, n, v->n_mels, v->d_mean, v->d_istd, v->feats.f(), v->in1.Kp, s);
-    const int keep = Tin - splice;                          // lfr_splice_cache_ = frames[splice:]
-    HIP_TRY(hipMemcpyAsync(vs->fb[vs->fb_cur ^ 1].p, fb + (size_t)splice * 80, (size_t)keep * 80 * 4, hipMemcpyDeviceToDevice, s));
-    vs->fb_cur ^= 1;
-    vs->n_splice = keep;
-    n_rows = n_out;
-    T = splice;                                             // lfr_splice_frame_idxs (returned by the reference)
-    return PFHIP_OK;
+    c.splice = std::min(Tin - 1, splice * n);
+    c.n_rows = n_out; c.Tin = Tin; c.run_lfr = true;
   };
-  if (frame_number > 0) {
-    waves.resize((size_t)(frame_number - 1) * fs + fl);
-    if (frame_number + vs->n_splice + (m - 1) / 2 > kVadMaxFrames) return fail(PFHIP_ERR_ARG, "too many frames in one online VAD call");
-    const bool fresh = vs->n_splice == 0;
-    const int base = fresh ? (m - 1) / 2 : vs->n_splice;
-    HIP_TRY(v->pcm.ensure(waves.size() * 4));
-    if (!v->h_wave(waves.size())) return fail(PFHIP_ERR_HIP, "pinned staging allocation failed");
-    std::memcpy(v->h_wave(waves.size()), waves.data(), waves.size() * 4);
-    HIP_TRY(hipMemcpyAsync(v->pcm.p, v->h_wave(0), waves.size() * 4, hipMemcpyHostToDevice, s));
-    {
-      int64_t* h64 = reinterpret_cast<int64_t*>(v->h_pin);
-      h64[0] = 0;
-      int* hm = v->h_pin + 2;
-      hm[0] = 0; hm[1] = frame_number; hm[2] = frame_number;
-      HIP_TRY(hipMemcpyAsync(v->meta.p, v->h_pin, 32, hipMemcpyHostToDevice, s));
-    }
-    pfhip::FbankTables tb{v->ft.d_window, v->ft.d_tw, v->ft.d_mel_off, v->ft.d_mel_size, v->ft.d_mel_w, v->d_mean, v->d_istd};
-    pfhip::launch_fbank_frames(v->pcm.f(), reinterpret_cast<int64_t*>(v->meta.p), v->meta.i() + 2, v->meta.i() + 4, frame_number,
-                               tb, fb + (size_t)base * 80, s);
-    // cache deal & online lfr, cmvn (:44-70)
-    const bool had_reserve = !vs->reserve.empty();
-    if (had_reserve) waves.insert(waves.begin(), vs->reserve.begin(), vs->reserve.end());
-    if (fresh) {                                            // lfr_splice_cache_ = (m-1)/2 copies of the first frame (:48-52)
-      for (int i = 0; i < base; ++i)
-        HIP_TRY(hipMemcpyAsync(fb + (size_t)i * 80, fb + (size_t)base * 80, 80 * 4, hipMemcpyDeviceToDevice, s));
-      vs->n_splice = base;
-    }
-    if (frame_number + vs->n_splice >= m) {
-      const int frame_from_waves = ((int)waves.size() - fl) / fs + 1;
+  c.out_off = r0; c.out_len = (size_t)total;
+  if (c.frame_number > 0) {
+    const size_t wlen = (size_t)(c.frame_number - 1) * fs + fl;
+    if (c.frame_number + vs->n_splice + (m - 1) / 2 > kVadMaxFrames) return fail(PFHIP_ERR_ARG, "too many frames in one online VAD call");
+    c.fb_off = r0; c.fb_len = wlen;
+    c.fresh = vs->n_splice == 0;
+    c.base = c.fresh ? (m - 1) / 2 : vs->n_splice;
+    const bool had_reserve = r0 > 0;
+    c.out_off = 0; c.out_len = r0 + wlen;                   // reserve_waveforms_ goes in front of what the scorer sees
+    const int n_splice = c.fresh ? c.base : vs->n_splice;   // (:48-52) fresh: (m-1)/2 copies of the first frame
+    if (c.frame_number + n_splice >= m) {
+      const int frame_from_waves = ((int)c.out_len - fl) / fs + 1;
       const int minus_frame = had_reserve ? 0 : (m - 1) / 2;
-      pfhip_status st = online_lfr(vs->n_splice + frame_number);
-      if (st) return st;
-      const int reserve_frame_idx = std::abs(T - minus_frame);
-      vs->reserve.assign(waves.begin() + (size_t)reserve_frame_idx * fs, waves.begin() + (size_t)frame_from_waves * fs);
-      waves.resize((size_t)(frame_from_waves - 1) * fs + fl);
+      online_lfr(n_splice + c.frame_number);
+      const int reserve_frame_idx = std::abs(c.splice - minus_frame);
+      vs->reserve.assign(c.buf + (size_t)reserve_frame_idx * fs, c.buf + (size_t)frame_from_waves * fs);
+      c.out_len = (size_t)(frame_from_waves - 1) * fs + fl;
     } else {
       // (:65-69) the splice cache just grows; the reference runs the network on the raw 80-dim frames here (a latent bug
       // reachable only with < 4 frames in a call): no rows in this restatement
-      vs->reserve.assign(waves.begin() + (fl - fs), waves.end());
-      vs->n_splice += frame_number;
+      vs->reserve.assign(c.buf + (fl - fs), c.buf + c.out_len);
     }
-  } else if (fin) {                                         // (:71-83)
-    if (!vs->reserve.empty()) waves = vs->reserve;
-    if (vs->n_splice > 0) {
-      pfhip_status st = online_lfr(vs->n_splice);
+  } else if (c.fin) {                                       // (:71-83)
+    if (r0) { c.out_off = 0; c.out_len = r0; }
+    if (vs->n_splice > 0) online_lfr(vs->n_splice);
+  }
+  return PFHIP_OK;
+}
+
+pfhip_status vad_execute(pfhip_vad* v, std::vector<VadCall>& calls) {
+  hipStream_t s = v->stream;
+  const int B = (int)calls.size(), m = v->lfr_m, n = v->lfr_n;
+  // ---- staging: [fbank meta | op lists | segment descriptors | samples of every connection | silence column] ---------------
+  size_t cap_samples = 0, cap_rows = 0;
+  for (VadCall& c : calls) {
+    const size_t have = c.vs->reserve.size() + c.vs->input_cache.size() + (size_t)c.n_samples;
+    cap_samples += have;
+    cap_rows += have / 160 + (size_t)c.vs->n_splice + 2;
+  }
+  const size_t meta_bytes = ((size_t)B * 8 + (size_t)(B + 1) * 4 + (size_t)B * 4 + 63) & ~(size_t)63;
+  const size_t ops_max = (size_t)(4 * B + 4) * 32;
+  const size_t ctl_bytes = meta_bytes + ops_max + (((size_t)B * sizeof(pfhip::VadSeg) + 63) & ~(size_t)63);
+  float* hp_f = v->h_wave(ctl_bytes / 4 + cap_samples + cap_rows + 64);
+  if (!hp_f) return fail(PFHIP_ERR_HIP, "pinned staging allocation failed");
+  char* hp = reinterpret_cast<char*>(hp_f);
+  float* h_pcm = reinterpret_cast<float*>(hp + ctl_bytes);
+  float* h_sil = h_pcm + cap_samples;
+  {
+    size_t so = 0;
+    for (VadCall& c : calls) {
+      c.buf = h_pcm + so;
+      so += c.vs->reserve.size() + c.vs->input_cache.size() + (size_t)c.n_samples;
+      pfhip_status st = vad_plan(c);
       if (st) return st;
     }
   }
-  const float* cin = vs->cache[vs->cache_cur].f();
-  if (fin) {
-    // (:84-87) Reset() + ResetCache() run inside ExtractFeats, BEFORE Forward (:143): the last call of a stream is scored
-    // against zeroed network caches, and nothing is carried over
-    vs->input_cache.clear(); vs->reserve.clear(); vs->n_splice = 0;
-    pfhip_status st = vs_zero_caches(vs, s);
-    if (st) return st;
+  // ---- fbank of all new audio in one launch ---------------------------------------------------------------------------
+  int total_frames = 0, U = 0, T = 0, max_T = 0;
+  for (VadCall& c : calls) {
+    if (c.frame_number > 0) { total_frames += c.frame_number; ++U; }
+    c.row_off = T; T += c.n_rows; max_T = std::max(max_T, c.n_rows);
   }
-  if ((size_t)waves.size() > waves_cap && waves_out) return fail(PFHIP_ERR_CAPACITY, "waves_out too small");
-  if (waves_out) std::memcpy(waves_out, waves.data(), waves.size() * 4);
-  *n_waves = (int)waves.size();
-  if (n_rows == 0) { HIP_TRY(hipStreamSynchronize(s)); return PFHIP_OK; }
-  if ((size_t)n_rows > cap_floats && sil_prob) return fail(PFHIP_ERR_CAPACITY, "sil_prob too small");
-  vad_network(v, s, n_rows, cin, fin ? nullptr : vs->cache[vs->cache_cur ^ 1].f());
-  if (!fin) vs->cache_cur ^= 1;
-  if (sil_prob) HIP_TRY(hipMemcpy2DAsync(sil_prob, 4, v->probs.p, (size_t)v->n_out * 4, 4, n_rows, hipMemcpyDeviceToHost, s));
+  if ((size_t)T > cap_rows) return fail(PFHIP_ERR_UNSUPPORTED, "online VAD row bound exceeded");
+  std::vector<pfhip::RowsCopyOp> to_fb, fresh, rotate;
+  std::vector<pfhip::VadLfrOp> lfr;
+  HIP_TRY(v->ops.ensure(ctl_bytes));
+  char* dp = static_cast<char*>(v->ops.p);
+  if (U > 0) {
+    HIP_TRY(v->pcm.ensure((cap_samples + 1024) * 4));
+    HIP_TRY(v->fbk.ensure((size_t)total_frames * 80 * 4));
+    int64_t* h_soff = reinterpret_cast<int64_t*>(hp);
+    int* h_foff = reinterpret_cast<int*>(hp + (size_t)U * 8);
+    int* h_nf = h_foff + (U + 1);
+    int fo = 0, u = 0;
+    for (VadCall& c : calls) {
+      if (c.frame_number <= 0) continue;
+      h_soff[u] = (int64_t)((c.buf - h_pcm) + c.fb_off); h_foff[u] = fo; h_nf[u] = c.frame_number;
+      float* fb = c.vs->fb[c.vs->fb_cur].f();
+      to_fb.push_back(pfhip::RowsCopyOp{fb + (size_t)c.base * 80, v->fbk.f() + (size_t)fo * 80, 80, 80, c.frame_number, 80});
+      if (c.fresh) fresh.push_back(pfhip::RowsCopyOp{fb, fb + (size_t)c.base * 80, 80, 0, c.base, 80});
+      fo += c.frame_number; ++u;
+    }
+    h_foff[U] = fo;
+    HIP_TRY(hipMemcpyAsync(v->pcm.p, h_pcm, cap_samples * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dp, hp, meta_bytes, hipMemcpyHostToDevice, s));
+    pfhip::FbankTables tb{v->ft.d_window, v->ft.d_tw, v->ft.d_mel_off, v->ft.d_mel_size, v->ft.d_mel_w, v->d_mean, v->d_istd};
+    pfhip::launch_fbank_frames_batch(v->pcm.f(), reinterpret_cast<const int64_t*>(dp), reinterpret_cast<const int*>(dp + (size_t)U * 8),
+                                     reinterpret_cast<const int*>(dp + (size_t)U * 8 + (size_t)(U + 1) * 4), U, total_frames, tb,
+                                     v->fbk.f(), s);
+  }
+  pfhip_status ws = vad_workspace(v, std::max(T, 1));
+  if (ws) return ws;
+  // ---- per-connection frame bookkeeping (splice caches) and the LFR rows, one launch per phase ---------------------------
+  std::vector<pfhip::VadSeg> segs;
+  for (VadCall& c : calls) {
+    pfhip_vad_stream* vs = c.vs;
+    if (c.frame_number > 0 && c.fresh) vs->n_splice = c.base;
+    if (c.run_lfr) {
+      const float* fb = vs->fb[vs->fb_cur].f();
+      if (c.n_rows > 0) lfr.push_back(pfhip::VadLfrOp{fb, c.Tin, c.n_rows, c.row_off, 0});
+      const int keep = c.Tin - c.splice;                    // lfr_splice_cache_ = frames[splice:]
+      rotate.push_back(pfhip::RowsCopyOp{vs->fb[vs->fb_cur ^ 1].f(), fb + (size_t)c.splice * 80, 80, 80, keep, 80});
+      vs->fb_cur ^= 1;
+      vs->n_splice = keep;
+    } else if (c.frame_number > 0) {
+      vs->n_splice += c.frame_number;                       // (:65-69) the splice cache just grows
+    }
+    // (:84-87) a final call: Reset() + ResetCache() run inside ExtractFeats, BEFORE Forward (:143) — scored against
+    // zeroed network caches, nothing carried over
+    if (c.fin) {
+      vs->input_cache.clear(); vs->reserve.clear(); vs->n_splice = 0;
+      pfhip_status st = vs_zero_caches(vs, s);
+      if (st) return st;
+    }
+    if (c.n_rows > 0)
+      segs.push_back(pfhip::VadSeg{vs->cache[vs->cache_cur].f(), c.fin ? nullptr : vs->cache[vs->cache_cur ^ 1].f(), c.row_off, c.n_rows});
+  }
+  char* h_ops = hp + meta_bytes;
+  char* d_ops = dp + meta_bytes;
+  size_t off = 0;
+  auto put = [&](const void* src, size_t nb) { const size_t at = off; if (nb) std::memcpy(h_ops + off, src, nb); off += nb; return at; };
+  const size_t o_fb = put(to_fb.data(), to_fb.size() * sizeof(pfhip::RowsCopyOp));
+  const size_t o_fr = put(fresh.data(), fresh.size() * sizeof(pfhip::RowsCopyOp));
+  const size_t o_lfr = put(lfr.data(), lfr.size() * sizeof(pfhip::VadLfrOp));
+  const size_t o_rot = put(rotate.data(), rotate.size() * sizeof(pfhip::RowsCopyOp));
+  const size_t o_seg = put(segs.data(), segs.size() * sizeof(pfhip::VadSeg));
+  if (off) HIP_TRY(hipMemcpyAsync(d_ops, h_ops, off, hipMemcpyHostToDevice, s));
+  auto max_rows = [](const std::vector<pfhip::RowsCopyOp>& o) { int mx = 0; for (const auto& x : o) mx = std::max(mx, x.nrows); return mx; };
+  pfhip::launch_rows_copy_batch(reinterpret_cast<const pfhip::RowsCopyOp*>(d_ops + o_fb), (int)to_fb.size(), max_rows(to_fb), s);
+  pfhip::launch_rows_copy_batch(reinterpret_cast<const pfhip::RowsCopyOp*>(d_ops + o_fr), (int)fresh.size(), max_rows(fresh), s);
+  pfhip::launch_lfr_cmvn_online_batch(reinterpret_cast<const pfhip::VadLfrOp*>(d_ops + o_lfr), (int)lfr.size(), max_T, m, n, v->n_mels,
+                                      v->d_mean, v->d_istd, v->feats.f(), v->in1.Kp, s);
+  pfhip::launch_rows_copy_batch(reinterpret_cast<const pfhip::RowsCopyOp*>(d_ops + o_rot), (int)rotate.size(), max_rows(rotate), s);
+  if (T > 0) {
+    vad_network(v, s, T, reinterpret_cast<const pfhip::VadSeg*>(d_ops + o_seg), (int)segs.size(), max_T);
+    for (VadCall& c : calls)
+      if (c.n_rows > 0 && !c.fin) c.vs->cache_cur ^= 1;
+  }
+  // ---- results: the silence column of all connections in one copy, handed out on the host --------------------------------------
+  if (T > 0) HIP_TRY(hipMemcpyAsync(h_sil, v->sil.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+  for (VadCall& c : calls) {
+    if (c.out_len > c.waves_cap && c.waves_out) return fail(PFHIP_ERR_CAPACITY, "waves_out too small");
+    if (c.waves_out && c.out_len) std::memcpy(c.waves_out, c.buf + c.out_off, c.out_len * 4);
+    *c.n_waves = (int)c.out_len;
+    if ((size_t)c.n_rows > c.cap_floats && c.sil_prob) return fail(PFHIP_ERR_CAPACITY, "sil_prob too small");
+    *c.n_frames = c.n_rows;
+  }
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
-  *n_frames = n_rows;
+  for (VadCall& c : calls)
+    if (c.n_rows > 0 && c.sil_prob) std::memcpy(c.sil_prob, h_sil + c.row_off, (size_t)c.n_rows * 4);
   return PFHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+pfhip_status pfhip_vad_stream_infer_batch(pfhip_vad_stream* const* streams, int n_streams, const float* const* pcm,
+                                          const int* n_samples, const int* input_finished, float* const* sil_prob,
+                                          const size_t* cap_floats, int* n_frames, float* const* waves_out,
+                                          const size_t* waves_cap, int* n_waves) {
+  last_error().clear();
+  if (!streams || n_streams <= 0 || !pcm || !n_samples || !input_finished || !sil_prob || !cap_floats || !n_frames || !waves_out ||
+      !waves_cap || !n_waves)
+    return fail(PFHIP_ERR_ARG, "bad argument");
+  pfhip_vad* v = streams[0] ? streams[0]->v : nullptr;
+  if (!v) return fail(PFHIP_ERR_ARG, "null stream");
+  std::vector<VadCall> calls(n_streams);
+  for (int i = 0; i < n_streams; ++i) {
+    if (!streams[i] || streams[i]->v != v) return fail(PFHIP_ERR_ARG, "streams of one batch must belong to one VAD model");
+    for (int j = 0; j < i; ++j) if (streams[j] == streams[i]) return fail(PFHIP_ERR_ARG, "a stream appears twice in one batch");
+    if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
+    if (n_samples[i] > kVadMaxSamples) return fail(PFHIP_ERR_ARG, "more than 64000 samples in one online VAD call");
+    calls[i].vs = streams[i]; calls[i].pcm = pcm[i]; calls[i].n_samples = n_samples[i]; calls[i].fin = input_finished[i] != 0;
+    calls[i].sil_prob = sil_prob[i]; calls[i].cap_floats = cap_floats[i]; calls[i].n_frames = &n_frames[i];
+    calls[i].waves_out = waves_out[i]; calls[i].waves_cap = waves_cap[i]; calls[i].n_waves = &n_waves[i];
+    n_frames[i] = 0; n_waves[i] = 0;
+  }
+  std::lock_guard<std::mutex> lk(v->mu);
+  HIP_TRY(hipSetDevice(v->device));
+  return vad_execute(v, calls);
+}
+
+pfhip_status pfhip_set_vad_stream_batching(pfhip_vad* v, int wait_us, int max_streams) {
+  last_error().clear();
+  if (!v || wait_us < 0 || max_streams < 1) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> ql(v->q_mu);
+  v->q_wait_us = wait_us;
+  v->q_max = max_streams;
+  return PFHIP_OK;
+}
+
+}  // extern "C"
+
+// One FsmnVadOnline::Infer per websocket handler thread (funasrruntime.cpp:516-532): with wait_us > 0 the first caller to
+// arrive leads, waits up to wait_us for the others and runs ONE pfhip_vad_stream_infer_batch for all of them.
+struct VadReq {
+  pfhip_vad_stream* vs; const float* pcm; int n; int fin; float* sil; size_t cap; int* nf; float* wo; size_t wcap; int* nw;
+  pfhip_status st = PFHIP_OK; std::string err; bool done = false;
+};
+
+namespace {
+
+pfhip_status vad_run_requests(const std::vector<VadReq*>& reqs) {
+  const int n = (int)reqs.size();
+  std::vector<pfhip_vad_stream*> ss(n);
+  std::vector<const float*> pcm(n);
+  std::vector<int> ns(n), fin(n), nf(n), nw(n);
+  std::vector<float*> sil(n), wo(n);
+  std::vector<size_t> cap(n), wcap(n);
+  for (int i = 0; i < n; ++i) {
+    const VadReq& r = *reqs[i];
+    ss[i] = r.vs; pcm[i] = r.pcm; ns[i] = r.n; fin[i] = r.fin; sil[i] = r.sil; cap[i] = r.cap; wo[i] = r.wo; wcap[i] = r.wcap;
+  }
+  const pfhip_status st = pfhip_vad_stream_infer_batch(ss.data(), n, pcm.data(), ns.data(), fin.data(), sil.data(), cap.data(),
+                                                       nf.data(), wo.data(), wcap.data(), nw.data());
+  for (int i = 0; i < n; ++i) { *reqs[i]->nf = nf[i]; *reqs[i]->nw = nw[i]; }
+  return st;
+}
+
+pfhip_status vad_infer_queued(pfhip_vad* v, VadReq& me) {
+  std::unique_lock<std::mutex> ql(v->q_mu);
+  v->queue.push_back(&me);
+  v->q_cv.notify_all();
+  while (!me.done) {
+    if (!v->q_leader_active && v->queue.front() == &me) {
+      v->q_leader_active = true;
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(v->q_wait_us);
+      while ((int)v->queue.size() < v->q_max && v->q_cv.wait_until(ql, deadline) != std::cv_status::timeout) {}
+      std::vector<VadReq*> take;
+      std::deque<VadReq*> later;
+      while (!v->queue.empty() && (int)take.size() < v->q_max) {
+        VadReq* r = v->queue.front();
+        v->queue.pop_front();
+        bool dup = false;                       // two queued calls on ONE connection stay in order: the second waits
+        for (VadReq* t : take) dup = dup || t->vs == r->vs;
+        if (dup) later.push_back(r); else take.push_back(r);
+      }
+      for (auto it = later.rbegin(); it != later.rend(); ++it) v->queue.push_front(*it);
+      ql.unlock();
+      const pfhip_status st = vad_run_requests(take);
+      const std::string err = pfhip_detail::last_error();
+      ql.lock();
+      for (VadReq* r : take) { r->st = st; r->err = err; r->done = true; }
+      v->q_leader_active = false;
+      v->q_cv.notify_all();
+    } else {
+      v->q_cv.wait(ql);
+    }
+  }
+  ql.unlock();
+  if (me.st != PFHIP_OK) pfhip_detail::last_error() = me.err;
+  return me.st;
+}
+
+}  // namespace
+
+extern "C" {
+
+pfhip_status pfhip_vad_stream_infer(pfhip_vad_stream* vs, const float* pcm, int n_samples, int input_finished, float* sil_prob,
+                                    size_t cap_floats, int* n_frames, float* waves_out, size_t waves_cap, int* n_waves) {
+  if (!vs || !n_frames || !n_waves) { last_error().clear(); return fail(PFHIP_ERR_ARG, "bad argument"); }
+  pfhip_vad* v = vs->v;
+  bool queued;
+  { std::lock_guard<std::mutex> ql(v->q_mu); queued = v->q_wait_us > 0 && v->q_max > 1; }
+  if (queued) {
+    VadReq me{vs, pcm, n_samples, input_finished, sil_prob, cap_floats, n_frames, waves_out, waves_cap, n_waves};
+    return vad_infer_queued(v, me);
+  }
+  const float* p[1] = {pcm};
+  float* sp[1] = {sil_prob};
+  float* wo[1] = {waves_out};
+  return pfhip_vad_stream_infer_batch(&vs, 1, p, &n_samples, &input_finished, sp, &cap_floats, n_frames, wo, &waves_cap, n_waves);
 }
 
 }  // extern "C"

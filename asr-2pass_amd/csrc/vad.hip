@@ -33,16 +33,22 @@ __global__ __launch_bounds__(128) void lfr_cmvn_kernel(const float* __restrict__
 
 // out[t][c] = p[t][c] + sum_{j<K} w[c][j] * xcat[t+j][c], xcat = [cache (K-1 rows); p (T rows)].
 // Time is tiled (kTT rows per block) with a K-row register window per thread (4 channels each).
+// blockIdx.z = connection (VadSeg): its rows [row_off, row_off + T) of the packed matrices, its own cache for this layer.
 template <int K>
-__global__ __launch_bounds__(64) void fsmn_causal_kernel(const float* __restrict__ p, int ldp,
+__global__ __launch_bounds__(64) void fsmn_causal_kernel(const float* __restrict__ p_all, int ldp,
                                                          const float* __restrict__ w,
-                                                         const float* __restrict__ cache, float* __restrict__ out,
-                                                         int ldo, int T, int C) {
+                                                         const VadSeg* __restrict__ segs, int layer,
+                                                         float* __restrict__ out_all, int ldo, int C) {
   constexpr int kTT = 32;
   const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
   if (c >= C) return;
+  const VadSeg sg = segs[blockIdx.z];
+  const int T = sg.T;
   const int t0 = blockIdx.x * kTT;
   if (t0 >= T) return;
+  const float* p = p_all + (size_t)sg.row_off * ldp;
+  float* out = out_all + (size_t)sg.row_off * ldo;
+  const float* cache = sg.cache_in + (size_t)layer * (K - 1) * C;
   float wk[4][K];
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch)
@@ -74,18 +80,24 @@ __global__ __launch_bounds__(64) void fsmn_causal_kernel(const float* __restrict
 }
 
 // new cache = last K-1 rows of [cache; p]
-__global__ __launch_bounds__(128) void fsmn_cache_update_kernel(const float* __restrict__ p, int ldp,
-                                                                const float* __restrict__ cache_in,
-                                                                float* __restrict__ cache_out, int T, int C,
+__global__ __launch_bounds__(128) void fsmn_cache_update_kernel(const float* __restrict__ p_all, int ldp,
+                                                                const VadSeg* __restrict__ segs, int layer, int C,
                                                                 int K1) {
+  const VadSeg sg = segs[blockIdx.y];
+  if (!sg.cache_out) return;                      // final call: caches are not advanced (fsmn-vad.cpp:129-134)
+  const float* p = p_all + (size_t)sg.row_off * ldp;
+  const float* cache_in = sg.cache_in + (size_t)layer * K1 * C;
+  float* cache_out = sg.cache_out + (size_t)layer * K1 * C;
+  const int T = sg.T;
   const int j = blockIdx.x;                       // row of the new cache, 0..K1-1
   const int src = T - K1 + j;                     // row of p, negative -> old cache row K1 + src
   for (int c = threadIdx.x; c < C; c += blockDim.x)
     cache_out[(size_t)j * C + c] = src >= 0 ? p[(size_t)src * ldp + c] : cache_in[(size_t)(K1 + src) * C + c];
 }
 
+// col0 (optional): the class-0 column alone, packed — the only score the end-point detector reads (e2e-vad.h:607-609)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, int M, int N,
-                                                           float* __restrict__ y) {
+                                                           float* __restrict__ y, float* __restrict__ col0) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -99,6 +111,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
   for (int c = lane; c < N; c += 64) y[(size_t)row * N + c] = expf(xr[c] - m) / s;
+  if (col0 && lane == 0) col0[row] = expf(xr[0] - m) / s;
 }
 
 }  // namespace
@@ -115,17 +128,44 @@ void launch_lfr_cmvn_online(const float* fb, int F, int T, int m, int n, int n_m
   hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(T), dim3(128), 0, s, fb, F, T, m, n, n_mels, mean, istd, out, ldo, 0);
 }
 
-void launch_fsmn_causal20(const float* p, int ldp, const float* w, const float* cache_in, float* cache_out, float* out,
-                          int ldo, int T, int C, hipStream_t s) {
-  if (T <= 0) return;
-  hipLaunchKernelGGL(fsmn_causal_kernel<20>, dim3((T + 31) / 32, (C + 255) / 256), dim3(64), 0, s, p, ldp, w, cache_in,
-                     out, ldo, T, C);
-  if (cache_out) hipLaunchKernelGGL(fsmn_cache_update_kernel, dim3(19), dim3(128), 0, s, p, ldp, cache_in, cache_out, T, C, 19);
+void launch_fsmn_causal20(const float* p, int ldp, const float* w, const VadSeg* segs, int B, int max_T, int layer, float* out,
+                          int ldo, int C, hipStream_t s) {
+  if (B <= 0 || max_T <= 0) return;
+  hipLaunchKernelGGL(fsmn_causal_kernel<20>, dim3((max_T + 31) / 32, (C + 255) / 256, B), dim3(64), 0, s, p, ldp, w, segs,
+                     layer, out, ldo, C);
+  hipLaunchKernelGGL(fsmn_cache_update_kernel, dim3(19, B), dim3(128), 0, s, p, ldp, segs, layer, C, 19);
 }
 
-void launch_softmax_rows(const float* x, int ldx, int M, int N, float* y, hipStream_t s) {
+// OnlineLfrCmvn rows of many connections in one launch: op i writes rows [row_off, row_off + n_out) of the packed matrix
+__global__ __launch_bounds__(128) void lfr_cmvn_online_batch_kernel(const VadLfrOp* __restrict__ ops, int m, int n, int n_mels,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ istd, float* __restrict__ out,
+                                                                    int ldo) {
+  const VadLfrOp op = ops[blockIdx.y];
+  const int i = blockIdx.x;
+  if (i >= op.n_out) return;
+  const int D = m * n_mels;
+  for (int c = threadIdx.x; c < ldo; c += blockDim.x) {
+    float v = 0.f;
+    if (c < D) {
+      const int j = c / n_mels, bin = c - j * n_mels;
+      int f = i * n + j;
+      f = f > op.Tin - 1 ? op.Tin - 1 : f;
+      v = (op.fb[(size_t)f * n_mels + bin] + mean[c]) * istd[c];
+    }
+    out[(size_t)(op.row_off + i) * ldo + c] = v;
+  }
+}
+
+void launch_lfr_cmvn_online_batch(const VadLfrOp* ops, int n_ops, int max_rows, int m, int n, int n_mels, const float* mean,
+                                  const float* istd, float* out, int ldo, hipStream_t s) {
+  if (n_ops <= 0 || max_rows <= 0) return;
+  hipLaunchKernelGGL(lfr_cmvn_online_batch_kernel, dim3(max_rows, n_ops), dim3(128), 0, s, ops, m, n, n_mels, mean, istd, out, ldo);
+}
+
+void launch_softmax_rows(const float* x, int ldx, int M, int N, float* y, float* col0, hipStream_t s) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, N, y);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, N, y, col0);
 }
 
 }  // namespace pfhip

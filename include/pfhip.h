@@ -200,6 +200,20 @@ pfhip_status pfhip_vad_stream_reset(pfhip_vad_stream* vs);
 pfhip_status pfhip_vad_stream_infer(pfhip_vad_stream* vs, const float* pcm, int n_samples, int input_finished, float* sil_prob,
                                     size_t cap_floats, int* n_frames, float* waves_out, size_t waves_cap, int* n_waves);
 
+/* The same call for n_streams connections of ONE pfhip_vad at once (arrays of the per-connection arguments above): the 2-pass
+ * server's websocket handlers each call FsmnVadOnline::Infer per 600 ms message (websocket-server-2pass.cpp:85-117 ->
+ * funasrruntime.cpp:516-532); issued together they share every launch (fbank, OnlineLfrCmvn rows, the 11 GEMMs, the FSMN
+ * memory with per-connection caches), so a round of N connections costs about what one call does.  Results are identical to
+ * n_streams separate calls.  A stream may appear only once per batch. */
+pfhip_status pfhip_vad_stream_infer_batch(pfhip_vad_stream* const* streams, int n_streams, const float* const* pcm,
+                                          const int* n_samples, const int* input_finished, float* const* sil_prob,
+                                          const size_t* cap_floats, int* n_frames, float* const* waves_out,
+                                          const size_t* waves_cap, int* n_waves);
+
+/* Merge concurrent pfhip_vad_stream_infer callers (one thread per connection, as the reference's websocket handlers are) into
+ * batched passes: wait_us > 0 and max_streams > 1 make the first caller wait up to wait_us for others.  Default: off. */
+pfhip_status pfhip_set_vad_stream_batching(pfhip_vad* v, int wait_us, int max_streams);
+
 /* ---- VAD end-point detector (host logic) -----------------------------------------------------------
  * `funasr::E2EVadModel` (onnxruntime/src/e2e-vad.h:268-783, WindowDetector :181-266, VADXOptions defaults :78-107)
  * restated on the host: sequential threshold / window logic over ~100 frames per second, no device work.

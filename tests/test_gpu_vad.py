@@ -94,3 +94,78 @@ def test_online_vad_matches_oracle_and_offline(pkg, weights_mod):
         assert np.abs(allp[:len(allp) - last] - off[:len(off) - last]).max() < 2e-5
         on.close()
     vad.close()
+
+
+def test_online_vad_batch_equals_separate_calls(pkg, weights_mod):
+    """pfhip_vad_stream_infer_batch over connections at different positions (first call, mid-stream, tiny message with no
+    rows, final call, empty final call) returns exactly what the same calls issued one by one return, round after round."""
+    man, blob = weights_mod.synth_vad_weights()
+    vad = pkg.FsmnVadHip().InitVad((man, blob))
+    rng = np.random.default_rng(21)
+    n = 6
+    pcm = [synth_pcm(2 + i % 3, 16000 * 3 + 977 * i, rng) for i in range(n)]
+    plans = [[9600] * 6, [16000, 300, 50, 4000, 23000], [3200] * 16, [200, 200, 9600, 9600, 30000], [48000], [9600] * 5 + [0]]
+    cuts = []
+    for i in range(n):
+        c = np.minimum(np.cumsum([0] + plans[i]), len(pcm[i]))
+        c = list(c)
+        if i != 5 and c[-1] < len(pcm[i]):
+            c.append(len(pcm[i]))
+        if i == 5:
+            c = list(np.minimum(np.cumsum([0] + plans[i][:-1]), len(pcm[i]))) + [len(pcm[i]), len(pcm[i])]
+        cuts.append(c)
+    a = [pkg.FsmnVadOnlineHip(vad) for _ in range(n)]
+    b = [pkg.FsmnVadOnlineHip(vad) for _ in range(n)]
+    rounds = max(len(c) - 1 for c in cuts)
+    total_rows = 0
+    for r in range(rounds):
+        live = [i for i in range(n) if r < len(cuts[i]) - 1]
+        chunks = [pcm[i][cuts[i][r]:cuts[i][r + 1]] for i in live]
+        fins = [r == len(cuts[i]) - 2 for i in live]
+        got = pkg.FsmnVadOnlineHip.InferScoresBatch([a[i] for i in live], chunks, fins)
+        for k, i in enumerate(live):
+            sil, wv = b[i].InferScores(chunks[k], fins[k])
+            assert np.array_equal(got[k][1], wv), (r, i)
+            assert got[k][0].shape == sil.shape, (r, i, got[k][0].shape, sil.shape)
+            assert np.array_equal(got[k][0], sil), (r, i, np.abs(got[k][0] - sil).max())
+            total_rows += sil.size
+    assert total_rows > 1000
+    with pytest.raises(RuntimeError):
+        pkg.FsmnVadOnlineHip.InferScoresBatch([a[0], a[0]], [pcm[0][:1600]] * 2, [False, False])
+    for x in a + b:
+        x.close()
+    vad.close()
+
+
+def test_online_vad_threads_are_merged(pkg, weights_mod):
+    """Eight connection threads calling Infer concurrently with merging on: every connection gets exactly the scores a
+    lone connection gets for the same audio."""
+    import threading
+    man, blob = weights_mod.synth_vad_weights()
+    vad = pkg.FsmnVadHip().InitVad((man, blob))
+    rng = np.random.default_rng(5)
+    pcm = [synth_pcm(2 + i % 2, 16000 * 2 + 500 * i, rng) for i in range(8)]
+
+    def run(i, on, out):
+        res = []
+        for k in range(0, len(pcm[i]), 9600):
+            res.append(on.InferScores(pcm[i][k:k + 9600], k + 9600 >= len(pcm[i]))[0])
+        out[i] = np.concatenate(res)
+
+    alone = {}
+    for i in range(8):
+        on = pkg.FsmnVadOnlineHip(vad)
+        run(i, on, alone)
+        on.close()
+    vad.set_stream_batching(2000, 8)
+    merged = {}
+    ons = [pkg.FsmnVadOnlineHip(vad) for _ in range(8)]
+    th = [threading.Thread(target=run, args=(i, ons[i], merged)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    vad.set_stream_batching(0, 1)
+    for i in range(8):
+        assert np.array_equal(alone[i], merged[i]), i
+    for on in ons:
+        on.close()
+    vad.close()

@@ -10,6 +10,7 @@
 #include <numeric>
 #include <sstream>
 
+#include "ct_transformer_hip.h"
 #include "paraformer_hip.h"
 #include "tpass_audio.h"
 
@@ -20,6 +21,8 @@ struct OfflineStreamHip {
   pfhip_vad* vad = nullptr;
   std::mutex vad_mu;            // FsmnVad keeps per-file caches: one file at a time, like the reference's per-call Reset
   float speech_noise_thres = 0.9f;       // vad.yaml default the reference passes (fsmn-vad.cpp:251-254)
+  std::unique_ptr<funasr::PuncModelHipBase> punc;      // OfflineStream::punc_handle (offline-stream.cpp:105-129)
+  std::mutex punc_mu;
   ~OfflineStreamHip() { if (vad) pfhip_vad_destroy(vad); }
 };
 
@@ -121,6 +124,8 @@ FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int
       std::exit(-1);
     }
   }
+  if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
+    os->punc.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, false));       // always CTTransformer here
   return os.release();
 }
 
@@ -195,6 +200,10 @@ FUNASR_RESULT FunOfflineInferBuffer(FUNASR_HANDLE handle, const char* sz_buf, in
     cur_stamp.erase(cur_stamp.size() - 1);
     res->stamp = cur_stamp + "]";
   }
+  if (os->punc) {                                                                      // funasrruntime.cpp:317-320
+    std::lock_guard<std::mutex> lk(os->punc_mu);
+    res->msg = os->punc->AddPunc(res->msg.c_str(), "zh-cn");
+  }
   return res.release();
 }
 
@@ -224,6 +233,8 @@ struct TpassStreamHip {               // funasr::TpassStream (tpass-stream.cpp):
   funasr::ParaformerHip asr, asr_online;
   pfhip_vad* vad = nullptr;
   float speech_noise_thres = 0.9f;
+  std::unique_ptr<funasr::PuncModelHipBase> punc_online;      // TpassStream::punc_online_handle (tpass-stream.cpp:100-135)
+  std::mutex punc_mu;
   ~TpassStreamHip() { if (vad) pfhip_vad_destroy(vad); }
 };
 
@@ -269,6 +280,8 @@ FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int t
   init(ts->asr, model_path[MODEL_DIR]);
   init(ts->asr_online, model_path[ONLINE_MODEL_DIR]);
   ts->vad = LoadVad(model_path[VAD_DIR]);
+  if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
+    ts->punc_online.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, true));   // realtime or offline class
   // one handler thread per connection in the server: merge their concurrent device calls into batched passes
   if (thread_num > 1) {
     pfhip_set_stream_batching(ts->asr_online.Handle(), 3000, 128);
@@ -296,12 +309,13 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
                                   std::vector<std::vector<std::string>>& punc_cache, bool input_finished, int sampling_rate,
                                   std::string wav_format, ASR_TYPE mode, const std::vector<std::vector<float>>& hw_emb, bool itn,
                                   int vad_tail_sil, int vad_max_len, FUNASR_DEC_HANDLE dec_handle) {
-  (void)punc_cache; (void)itn; (void)dec_handle;
+  (void)itn; (void)dec_handle;
   TpassStreamHip* ts = static_cast<TpassStreamHip*>(handle);
   TpassOnlineStreamHip* os = static_cast<TpassOnlineStreamHip*>(online_handle);
   if (!ts || !os || !sz_buf) return nullptr;
   if (wav_format != "pcm" && wav_format != "PCM") return nullptr;                  // funasrruntime.cpp:523-531
   if (sampling_rate != 16000) return nullptr;
+  if (ts->punc_online && punc_cache.size() < 2) return nullptr;                    // [0]: online text, [1]: 2nd-pass text
   if (!os->audio.LoadPcmwavOnline(sz_buf, n_len)) return nullptr;
   auto res = std::make_unique<RecogResult>();
   res->snippet_time = os->audio.GetTimeLen();
@@ -337,7 +351,14 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
       std::fprintf(stderr, "FunTpassInferBuffer: %s\n", pfhip_last_error());
     if (mode == ASR_ONLINE) {
       os->online_res += msg;
-      if (frame.is_final) { res->tpass_msg = os->online_res; os->online_res.clear(); }
+      if (frame.is_final) {                                                         // funasrruntime.cpp:543-556
+        res->tpass_msg = os->online_res;
+        if (ts->punc_online) {
+          std::lock_guard<std::mutex> lk(ts->punc_mu);
+          res->tpass_msg = ts->punc_online->AddPunc(os->online_res.c_str(), punc_cache[0]);
+        }
+        os->online_res.clear();
+      }
       res->msg += msg;
     } else if (mode == ASR_TWO_PASS) {
       res->msg += msg;
@@ -367,6 +388,11 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
       res->stamp += cur_stamp + "]";
     }
     res->tpass_msg = msg;
+    if (ts->punc_online) {                                                          // funasrruntime.cpp:609-614
+      std::lock_guard<std::mutex> lk(ts->punc_mu);
+      res->tpass_msg = ts->punc_online->AddPunc(msg.c_str(), punc_cache[1]);
+      if (input_finished && ts->punc_online->is_online) res->tpass_msg += "\xE3\x80\x82";      // "。"
+    }
   }
   if (input_finished) os->audio.ResetIndex();
   return res.release();

@@ -9,9 +9,9 @@
 //   FunOfflineUninit        funasrruntime.cpp:806-814
 //
 // Stand-alone mirror: inside the reference tree the real funasrruntime.cpp stays and only the Model classes are swapped
-// (INTEGRATION.md).  What is NOT here is the text side of the reference function: audio container decode (ffmpeg), CT-
-// Transformer text re-segmentation (`AddPunc`, ct-transformer.cpp:39-155), ITN and sentence stamps — SURVEY §8 keeps
-// those above the hot path.  Result text = the vocabulary strings of the greedy tokens (or space-separated ids without
+// (INTEGRATION.md).  With PUNC_DIR given the text goes through CTTransformerHip::AddPunc like the reference's punc_handle
+// (funasrruntime.cpp:317-320).  What is NOT here: audio container decode (ffmpeg), ITN (WFST text normaliser) and sentence
+// stamps — text handling above the hot path.  Result text = the vocabulary strings of the greedy tokens (or space-separated ids without
 // a tokens.json); stamps have the reference's "[[b,e],[b,e]...]" millisecond format.
 #pragma once
 #include <map>
@@ -22,6 +22,7 @@
 #define VAD_DIR "vad-dir"
 #define TOKEN_PATH "token-path"
 #define ONLINE_MODEL_DIR "online-model-dir"
+#define PUNC_DIR "punc-dir"
 
 typedef void* FUNASR_HANDLE;
 typedef void* FUNASR_RESULT;
@@ -53,7 +54,9 @@ void FunOfflineUninit(FUNASR_HANDLE handle);
 //   FunTpassOnlineInit   TpassOnlineStream: one per connection — ParaformerOnline stream, FsmnVadOnline, Audio
 //   FunTpassInferBuffer  LoadPcmwavOnline -> Split (online VAD) -> streaming Forward per chunk -> offline Forward per closed
 //                        segment; msg = text of this call's streaming chunks, tpass_msg = 2nd-pass text of a segment that
-//                        closed in this call (punctuation / ITN of the reference are text handling above the path)
+//                        closed in this call; with PUNC_DIR both go through punc_online_handle->AddPunc with punc_cache[0] /
+//                        punc_cache[1] as in the reference (:543-556, :609-614) — the realtime class when the directory
+//                        name contains "realtime" (tpass-stream.cpp:124-134)
 FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int thread_num);
 FUNASR_HANDLE FunTpassOnlineInit(FUNASR_HANDLE tpass_handle, std::vector<int> chunk_size = {5, 10, 5});
 FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_handle, const char* sz_buf, int n_len,

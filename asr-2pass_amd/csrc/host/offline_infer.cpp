@@ -15,12 +15,13 @@
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s model_dir vad_dir|- pcm_s16_file [batch] [threads] [repeat]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s model_dir vad_dir|- pcm_s16_file [batch] [threads] [repeat] [punc_dir]\n", argv[0]);
     return 2;
   }
   std::map<std::string, std::string> paths;
   paths[MODEL_DIR] = argv[1];
   if (std::string(argv[2]) != "-") paths[VAD_DIR] = argv[2];
+  if (argc > 7) paths[PUNC_DIR] = argv[7];
   const int batch = argc > 4 ? std::atoi(argv[4]) : 32, threads = argc > 5 ? std::atoi(argv[5]) : 1, repeat = argc > 6 ? std::atoi(argv[6]) : 1;
   std::ifstream f(argv[3], std::ios::binary);
   std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());

@@ -1,6 +1,6 @@
 // Harness over the 2-pass handle API (funasrruntime_hip.h), one connection fed like the websocket server feeds it
 // (websocket/bin/websocket-server-2pass.cpp:135-148: 9600-sample pieces, the last one with input_finished):
-//   tpass_infer <offline_model_dir> <online_model_dir> <vad_dir> <pcm_s16_file> [step_samples=9600] [mode=2]
+//   tpass_infer <offline_model_dir> <online_model_dir> <vad_dir> <pcm_s16_file> [step_samples=9600] [mode=2] [punc_dir]
 // One line per call: "call <j> | online <text> | tpass <text> | stamp <stamp>".
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
   }
   std::map<std::string, std::string> paths;
   paths[MODEL_DIR] = argv[1]; paths[ONLINE_MODEL_DIR] = argv[2]; paths[VAD_DIR] = argv[3];
+  if (argc > 7) paths[PUNC_DIR] = argv[7];
   const int step = argc > 5 ? std::atoi(argv[5]) : 9600;
   const ASR_TYPE mode = argc > 6 ? (ASR_TYPE)std::atoi(argv[6]) : ASR_TWO_PASS;
   std::ifstream f(argv[4], std::ios::binary);

@@ -202,3 +202,67 @@ def test_cpp_2pass_api_matches_python_flow(pkg, weights_mod, tmp_path):
     assert n_calls == len(got) and n_tpass >= 3                 # several segments closed and were re-decoded offline
     for o in (vad_on, stream, vad, asr, asr_on_model):
         o.close()
+
+
+def test_cpp_2pass_api_with_punctuation(pkg, weights_mod, tmp_path):
+    """FunTpassInferBuffer with a PUNC_DIR: the 2nd-pass text of every closed segment goes through
+    punc_online_handle->AddPunc(msg, punc_cache[1]) (funasrruntime.cpp:609-614) — the realtime class (cache carried from
+    segment to segment, "。" appended on the final call) when the directory name contains "realtime", else CTTransformer.
+    Expected texts: the un-punctuated run of the same harness pushed through the oracle's AddPunc restatements."""
+    import json
+    import os
+    import subprocess
+    from oracle import ct_transformer as C
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    rng = np.random.default_rng(23)
+    pcm = make_file(rng)[:16000 * 30]
+    s16 = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2")
+    vman, vblob = shape_vad_weights(*weights_mod.synth_vad_weights())
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=1, vocab=300)
+    aman, ablob = weights_mod.synth_weights(cfg, seed=31)
+    oman, oblob = weights_mod.synth_weights(cfg, seed=32)
+    vocab = ["<blank>", "<s>", "</s>"] + [chr(0x4E00 + i) for i in range(296)] + ["<unk>"]
+    pcfg = dict(weights_mod.CT_TRANSFORMER, vocab=len(vocab))
+    pman, pblob = weights_mod.synth_punc_weights(pcfg)
+    dirs = {k: tmp_path / k for k in ("asr", "online", "vad", "punc", "punc_realtime")}
+    for d in dirs.values():
+        d.mkdir()
+    weights_mod.save(str(dirs["asr"] / "model.pfhip"), aman, ablob)
+    weights_mod.save(str(dirs["online"] / "model.pfhip"), oman, oblob)
+    weights_mod.save(str(dirs["vad"] / "vad.pfhip"), vman, vblob)
+    for k in ("asr", "online", "punc", "punc_realtime"):
+        with open(dirs[k] / "tokens.json", "w", encoding="utf-8") as f:
+            json.dump(vocab, f, ensure_ascii=False)               # raw UTF-8, as FunASR writes it
+    for k in ("punc", "punc_realtime"):
+        weights_mod.save(str(dirs[k] / "punc.pfhip"), pman, pblob)
+    s16.tofile(tmp_path / "stream.pcm")
+    exe = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "tpass_infer")
+    base = [exe, str(dirs["asr"]), str(dirs["online"]), str(dirs["vad"]), str(tmp_path / "stream.pcm"), "9600", "2"]
+
+    def run(*extra):
+        out = subprocess.run(base + list(extra), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        return [l.split(" | ") for l in out.stdout.splitlines() if l.startswith("call ")]
+
+    plain = run()
+    off = run(str(dirs["punc"]))
+    real = run(str(dirs["punc_realtime"]))
+    assert len(plain) == len(off) == len(real)
+    W = P.Weights(pman, pblob)
+    t2i = {t: i for i, t in enumerate(vocab)}
+    infer_off = lambda ids: C.infer(np.asarray(ids, np.int32), W)[1]
+    infer_on = lambda ids, n_cache: C.forward_online(np.asarray(ids, np.int32), W, n_cache)[1]
+    cache, n_seg = [], 0
+    for j, (p, o, r) in enumerate(zip(plain, off, real)):
+        assert p[1] == o[1] == r[1]                               # streaming text is not punctuated in 2-pass mode
+        text = p[2][len("tpass "):]
+        if not text:
+            assert o[2] == "tpass " and r[2] == "tpass "
+            continue
+        n_seg += 1
+        last = j == len(plain) - 1
+        assert o[2] == "tpass " + C.add_punc_text(text, infer_off, t2i), j
+        want = C.add_punc_text_online(text, cache, infer_on, t2i) + ("。" if last else "")
+        assert r[2] == "tpass " + want, (j, r[2], want)
+    assert n_seg >= 3

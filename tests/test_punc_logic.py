@@ -58,3 +58,65 @@ def test_forced_period_at_last_comma_beyond_200_carried_tokens():
     assert calls[:11] == [20 * k for k in range(1, 12)]
     assert calls[11] == 2 + 20        # after the cut at index 217 of 220 two tokens remain
     assert out.count(PERIOD) >= 2
+
+
+# ---- text level: CTokenizer::Tokenize + string assembly, hand-derived known answers ---------------------------------------------
+T2I = {"<unk>": 0, "你": 1, "好": 2, "hello": 3, "world": 4, "吗": 5}
+
+
+def test_tokenize_splits_ascii_runs_and_utf8_characters():
+    words, ids = C.tokenize("你好Hello  world吗x", T2I)
+    assert [w.decode() for w in words] == ["你", "好", "Hello", "world", "吗", "x"]
+    assert ids == [1, 2, 3, 4, 5, 0]                    # looked up lower-cased; the words keep their case; unknown -> <unk>
+    assert C.tokenize("", T2I) == ([], [])
+    assert C.tokenize("   ", T2I) == ([], [])
+
+
+def test_offline_text_assembly():
+    # punctuation after 好 and a forced final period; ASCII neighbours are separated by one blank
+    def infer(ids):
+        return [COMMA if i == 2 else NOT for i in ids]
+    assert C.add_punc_text("你好hello world", infer, T2I) == "你好，hello world。"
+    assert C.add_punc_text("你好", infer, T2I) == "你好。"                      # trailing comma becomes the period
+    assert C.add_punc_text("hello world", lambda ids: [NOT, QUESTION], T2I) == "hello world？"
+    assert C.add_punc_text("hello world", lambda ids: [NOT, QUESTION], T2I, language="en-bpe") == "hello world?"
+    assert C.add_punc_text("", infer, T2I) == ""
+
+
+def test_offline_no_blank_at_a_mini_sentence_start():
+    # 21 ASCII words, a period after word 10: the second Infer gets words 11..20; word 11 starts that mini-sentence and gets
+    # no blank in front of it (the k > 0 test is per mini-sentence, ct-transformer.cpp:98-103)
+    text = " ".join(f"w{i}" for i in range(21))
+    state = {"n": 0}
+
+    def infer(ids):
+        state["n"] += 1
+        p = [NOT] * len(ids)
+        if state["n"] == 1:
+            p[10] = PERIOD
+        return p
+
+    out = C.add_punc_text(text, infer, {"<unk>": 0})
+    assert out == " ".join(f"w{i}" for i in range(11)) + "。" + "w11 " + " ".join(f"w{i}" for i in range(12, 21)) + "。"
+
+
+def test_online_cache_roundtrip():
+    # first call: "你好吗" with ？ after 吗 (last position: not a cut point) -> everything is cached, the trailing mark is held back
+    cache = []
+    out = C.add_punc_text_online("你好吗", cache, lambda ids, n: [NOT, NOT, QUESTION], T2I)
+    assert out == "你好吗" and [w.decode() for w in cache] == ["你", "好", "吗"]
+    # second call: cached words are skipped in the output, but the mark of the LAST cached word is emitted (nSkipNum rule)
+    seen = []
+
+    def infer(ids, n_cache):
+        seen.append((list(ids), n_cache))
+        return [NOT, NOT, QUESTION, NOT, PERIOD, NOT]
+
+    out = C.add_punc_text_online("hello world你", cache, infer, T2I)
+    assert seen == [([1, 2, 5, 3, 4, 1], 3)]
+    assert out == "？hello world。你"
+    assert [w.decode() for w in cache] == ["你"]          # words after the last sentence end
+    # ASCII cache tail + ASCII input: a blank is inserted at the junction (ct-transformer-online.cpp:48-50)
+    cache = [b"hello"]
+    out = C.add_punc_text_online("world", cache, lambda ids, n: [NOT, NOT], T2I)
+    assert out == "world" and cache == [b"hello ", b"world"]

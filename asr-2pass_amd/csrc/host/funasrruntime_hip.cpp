@@ -11,6 +11,7 @@
 #include <sstream>
 
 #include "ct_transformer_hip.h"
+#include "fsmn_vad_hip.h"
 #include "paraformer_hip.h"
 #include "tpass_audio.h"
 
@@ -18,12 +19,10 @@ namespace {
 
 struct OfflineStreamHip {
   funasr::ParaformerHip asr;
-  pfhip_vad* vad = nullptr;
+  std::unique_ptr<funasr::FsmnVadHip> vad;
   std::mutex vad_mu;            // FsmnVad keeps per-file caches: one file at a time, like the reference's per-call Reset
-  float speech_noise_thres = 0.9f;       // vad.yaml default the reference passes (fsmn-vad.cpp:251-254)
   std::unique_ptr<funasr::PuncModelHipBase> punc;      // OfflineStream::punc_handle (offline-stream.cpp:105-129)
   std::mutex punc_mu;
-  ~OfflineStreamHip() { if (vad) pfhip_vad_destroy(vad); }
 };
 
 struct RecogResult {               // funasr::FUNASR_RECOG_RESULT (com-define.h)
@@ -47,30 +46,19 @@ constexpr int kSegSample = 16;      // samples per ms at 16 kHz (audio.cpp: seg_
 
 // Audio::CutSplit (audio.cpp:1172-1240): the FSMN-VAD scores the whole buffer in one pass (it is causal: the reference's
 // 1-s slices carry the same cache state), the end-point detector runs on the host, segments come back in ms.
-bool CutSplit(OfflineStreamHip* os, const std::vector<float>& pcm, int vad_tail_sil, int vad_max_len,
+bool CutSplit(OfflineStreamHip* os, std::vector<float>& pcm, int vad_tail_sil, int vad_max_len,
               std::vector<std::pair<int, int>>& frames, std::vector<int>& index_vector) {
   frames.clear();
   index_vector.clear();
   const int n = (int)pcm.size();
-  const int max_frames = n >= 400 ? (n - 400) / 160 + 1 : 0;
-  if (max_frames <= 0) return true;
-  std::vector<float> sil((size_t)max_frames + 8);
-  int T = 0;
-  std::lock_guard<std::mutex> lk(os->vad_mu);
-  if (pfhip_vad_reset(os->vad) != PFHIP_OK) return false;
-  if (pfhip_vad_forward_sil(os->vad, pcm.data(), n, 1, sil.data(), sil.size(), &T) != PFHIP_OK) return false;
-  if (T <= 0) return true;
-  pfhip_vadseg* seg = nullptr;
-  if (pfhip_vadseg_create(&seg) != PFHIP_OK) return false;
-  const int n_used = 400 + 160 * (T - 1);
-  std::vector<int32_t> pairs((size_t)2 * (T / 2 + 8));
-  int n_seg = 0;
-  const pfhip_status st = pfhip_vadseg_feed(seg, sil.data(), T, pcm.data(), std::min(n_used, n), 1, 0, vad_tail_sil, vad_max_len,
-                                            os->speech_noise_thres, 16000, pairs.data(), (int)pairs.size() / 2, &n_seg);
-  pfhip_vadseg_destroy(seg);
-  if (st != PFHIP_OK) return false;
-  for (int i = 0; i < n_seg; ++i)
-    frames.emplace_back(pairs[2 * i] * kSegSample, std::min(pairs[2 * i + 1] * kSegSample, n));
+  std::vector<std::vector<int>> segs;
+  {
+    std::lock_guard<std::mutex> lk(os->vad_mu);
+    os->vad->Reset();
+    os->vad->SetConfig(vad_tail_sil, vad_max_len);
+    segs = os->vad->Infer(pcm, true);
+  }
+  for (const std::vector<int>& sg : segs) frames.emplace_back(sg[0] * kSegSample, std::min(sg[1] * kSegSample, n));
   index_vector.resize(frames.size());
   std::iota(index_vector.begin(), index_vector.end(), 0);
   // audio.cpp:1226-1239: queue by increasing length (ties keep time order)
@@ -113,16 +101,8 @@ FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int
   os->asr.InitAsr(dir + "/model.pfhip.bin", "", dir + "/model.pfhip.json", tok, thread_num);      // exits on failure
   os->asr.SetBatchSize(batch_size);
   if (model_path.count(VAD_DIR) && !model_path[VAD_DIR].empty()) {
-    std::vector<char> blob, man;
-    if (!ReadAll(model_path[VAD_DIR] + "/vad.pfhip.bin", blob) || !ReadAll(model_path[VAD_DIR] + "/vad.pfhip.json", man)) {
-      std::fprintf(stderr, "Error when load vad hip model: cannot read %s\n", model_path[VAD_DIR].c_str());
-      std::exit(-1);                     // fsmn-vad.cpp:30-33
-    }
-    man.push_back('\0');
-    if (pfhip_vad_create_from_memory(blob.data(), blob.size(), man.data(), 0, &os->vad) != PFHIP_OK) {
-      std::fprintf(stderr, "Error when load vad hip model: %s\n", pfhip_last_error());
-      std::exit(-1);
-    }
+    os->vad.reset(new funasr::FsmnVadHip());
+    os->vad->InitVad(model_path[VAD_DIR] + "/vad.pfhip.bin", "", model_path[VAD_DIR] + "/vad.pfhip.json", thread_num);   // exits on failure
   }
   if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
     os->punc.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, false));       // always CTTransformer here
@@ -231,42 +211,22 @@ namespace {
 
 struct TpassStreamHip {               // funasr::TpassStream (tpass-stream.cpp): the shared models
   funasr::ParaformerHip asr, asr_online;
-  pfhip_vad* vad = nullptr;
-  float speech_noise_thres = 0.9f;
+  funasr::FsmnVadHip vad;
   std::unique_ptr<funasr::PuncModelHipBase> punc_online;      // TpassStream::punc_online_handle (tpass-stream.cpp:100-135)
   std::mutex punc_mu;
-  ~TpassStreamHip() { if (vad) pfhip_vad_destroy(vad); }
 };
 
 struct TpassOnlineStreamHip {         // funasr::TpassOnlineStream (tpass-online-stream.cpp:14-15): per connection
   TpassStreamHip* shared = nullptr;
   pfhip_stream* asr_online = nullptr;
-  pfhip_vad_stream* vad_online = nullptr;
-  pfhip_vadseg* scorer = nullptr;
+  std::unique_ptr<funasr::FsmnVadOnlineHip> vad_online;
   pfhip_host::TpassAudio audio;
   int chunk_len = 9600;
   std::string online_res;
   ~TpassOnlineStreamHip() {
     if (asr_online) pfhip_stream_destroy(asr_online);
-    if (vad_online) pfhip_vad_stream_destroy(vad_online);
-    if (scorer) pfhip_vadseg_destroy(scorer);
   }
 };
-
-pfhip_vad* LoadVad(const std::string& dir) {
-  std::vector<char> blob, man;
-  if (!ReadAll(dir + "/vad.pfhip.bin", blob) || !ReadAll(dir + "/vad.pfhip.json", man)) {
-    std::fprintf(stderr, "Error when load vad hip model: cannot read %s\n", dir.c_str());
-    std::exit(-1);
-  }
-  man.push_back('\0');
-  pfhip_vad* v = nullptr;
-  if (pfhip_vad_create_from_memory(blob.data(), blob.size(), man.data(), 0, &v) != PFHIP_OK) {
-    std::fprintf(stderr, "Error when load vad hip model: %s\n", pfhip_last_error());
-    std::exit(-1);
-  }
-  return v;
-}
 
 }  // namespace
 
@@ -279,13 +239,13 @@ FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int t
   };
   init(ts->asr, model_path[MODEL_DIR]);
   init(ts->asr_online, model_path[ONLINE_MODEL_DIR]);
-  ts->vad = LoadVad(model_path[VAD_DIR]);
+  ts->vad.InitVad(model_path[VAD_DIR] + "/vad.pfhip.bin", "", model_path[VAD_DIR] + "/vad.pfhip.json", thread_num);   // exits on failure
   if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
     ts->punc_online.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, true));   // realtime or offline class
   // one handler thread per connection in the server: merge their concurrent device calls into batched passes
   if (thread_num > 1) {
     pfhip_set_stream_batching(ts->asr_online.Handle(), 3000, 128);
-    if (ts->vad) pfhip_set_vad_stream_batching(ts->vad, 1000, 256);
+    pfhip_set_vad_stream_batching(ts->vad.Handle(), 1000, 256);
   }
   return ts.release();
 }
@@ -295,8 +255,8 @@ FUNASR_HANDLE FunTpassOnlineInit(FUNASR_HANDLE tpass_handle, std::vector<int> ch
   if (!ts || chunk_size.size() != 3) return nullptr;
   auto os = std::make_unique<TpassOnlineStreamHip>();
   os->shared = ts;
-  if (pfhip_stream_create(ts->asr_online.Handle(), chunk_size.data(), &os->asr_online) != PFHIP_OK ||
-      pfhip_vad_stream_create(ts->vad, &os->vad_online) != PFHIP_OK || pfhip_vadseg_create(&os->scorer) != PFHIP_OK) {
+  os->vad_online.reset(new funasr::FsmnVadOnlineHip(&ts->vad));
+  if (pfhip_stream_create(ts->asr_online.Handle(), chunk_size.data(), &os->asr_online) != PFHIP_OK || !os->vad_online->ok()) {
     std::fprintf(stderr, "FunTpassOnlineInit: %s\n", pfhip_last_error());
     return nullptr;
   }
@@ -320,24 +280,8 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
   auto res = std::make_unique<RecogResult>();
   res->snippet_time = os->audio.GetTimeLen();
   // FsmnVadOnline::Infer (fsmn-vad-online.cpp:135-151) as the VAD of Audio::Split
-  auto vad_infer = [&](std::vector<float>& waves, bool fin) -> std::vector<std::vector<int>> {
-    std::vector<float> sil(waves.size() / 160 + 16), wv(waves.size() + 4096);
-    int nf = 0, nw = 0;
-    if (pfhip_vad_stream_infer(os->vad_online, waves.data(), (int)waves.size(), fin ? 1 : 0, sil.data(), sil.size(), &nf, wv.data(),
-                               wv.size(), &nw) != PFHIP_OK) {
-      std::fprintf(stderr, "FunTpassInferBuffer: %s\n", pfhip_last_error());
-      return {};
-    }
-    if (nf == 0) return {};
-    std::vector<int32_t> pairs((size_t)2 * (nf + 8));
-    int n_seg = 0;
-    if (pfhip_vadseg_feed(os->scorer, sil.data(), nf, wv.data(), nw, fin ? 1 : 0, 1, vad_tail_sil, vad_max_len, ts->speech_noise_thres,
-                          16000, pairs.data(), (int)pairs.size() / 2, &n_seg) != PFHIP_OK)
-      return {};
-    std::vector<std::vector<int>> out;
-    for (int i = 0; i < n_seg; ++i) out.push_back({pairs[2 * i], pairs[2 * i + 1]});
-    return out;
-  };
+  os->vad_online->SetConfig(vad_tail_sil, vad_max_len);
+  auto vad_infer = [&](std::vector<float>& waves, bool fin) { return os->vad_online->Infer(waves, fin); };
   os->audio.Split(vad_infer, os->chunk_len, input_finished, (pfhip_host::AsrType)mode);
   pfhip_host::TpassFrame frame;
   while (os->audio.FetchChunck(frame)) {                                            // funasrruntime.cpp:538-566

@@ -244,8 +244,11 @@ FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int t
     ts->punc_online.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, true));   // realtime or offline class
   // one handler thread per connection in the server: merge their concurrent device calls into batched passes
   if (thread_num > 1) {
-    pfhip_set_stream_batching(ts->asr_online.Handle(), 3000, 128);
-    pfhip_set_vad_stream_batching(ts->vad.Handle(), 1000, 256);
+    auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    pfhip_set_stream_batching(ts->asr_online.Handle(), knob("PFHIP_STREAM_WAIT_US", 3000), knob("PFHIP_STREAM_MAX", 128));
+    pfhip_set_vad_stream_batching(ts->vad.Handle(), knob("PFHIP_VAD_WAIT_US", 1000), knob("PFHIP_VAD_MAX", 256));
+    if (std::getenv("PFHIP_OFFLINE_WAIT_US"))
+      pfhip_set_batching(ts->asr.Handle(), knob("PFHIP_OFFLINE_WAIT_US", 3000), knob("PFHIP_OFFLINE_MAX", 96));
   }
   return ts.release();
 }

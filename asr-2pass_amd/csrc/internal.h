@@ -15,6 +15,7 @@
 
 #include "../../include/pfhip.h"
 #include "kernels.h"
+#include "merge_queue.h"
 
 namespace pfhip_detail {
 
@@ -105,6 +106,7 @@ using pfhip_detail::ProfRec;
 using pfhip_detail::Tensor;
 
 struct BatchReq;
+struct StreamReq;
 
 struct pfhip_model {
   int device = 0;
@@ -149,18 +151,13 @@ struct pfhip_model {
   int64_t* m_sample_off = nullptr;
   int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr, *m_hw_off = nullptr, *m_hw_len = nullptr;
 
-  // cross-request batching (pfhip_set_batching): callers queue here, one of them leads a merged forward
-  std::mutex qmu;
-  std::condition_variable qcv;
-  std::deque<struct BatchReq*> queue;
-  bool leader_active = false;
+  // cross-request batching (pfhip_set_batching): callers queue here, one of them leads a merged forward (merge_queue.h)
+  pfhip_detail::MergeQueue<BatchReq> bq;
   int batch_wait_us = 0, batch_max_utts = 32;
   // the same for streaming calls: concurrent pfhip_stream_forward callers (one thread per connection) are merged
-  std::mutex sq_mu;
-  std::condition_variable sq_cv;
-  std::deque<struct StreamReq*> squeue;
-  bool sq_leader_active = false;
+  pfhip_detail::MergeQueue<StreamReq> sq;
   int stream_wait_us = 0, stream_max = 128;
+  std::atomic<int> live_streams{0};     // open pfhip_streams: a leader stops waiting once all of them have queued
 
   // profiling
   int prof_mask = 0;             // bit c set -> launches of kernel class c are bracketed by events

@@ -807,73 +807,66 @@ static pfhip_status forward_direct(pfhip_model* m, const float* const* pcm, cons
 // merged here: the first caller to arrive leads, waits up to `wait_us` for others, runs ONE packed forward for all
 // queued utterances and hands every caller its own slice.  Results are identical to separate calls (packed layout,
 // per-utterance masks: tests/test_gpu_forward.py::test_batch_composition_invariance).
-struct BatchReq {
+struct BatchReq : pfhip_detail::MergeReqBase {
   const float* const* pcm; const int* n; int batch; pfhip_out* out;
-  pfhip_status st = PFHIP_OK; std::string err; bool done = false;
+  pfhip_status st = PFHIP_OK; std::string err;
 };
+
+// one packed forward for everybody in `take`
+static void run_batch_requests(pfhip_model* m, const std::vector<BatchReq*>& take) {
+  std::vector<const float*> ptrs; std::vector<int> lens;
+  bool want_logp = false; int max_tok = 1, utts = 0;
+  for (BatchReq* r : take) {
+    for (int i = 0; i < r->batch; ++i) { ptrs.push_back(r->pcm[i]); lens.push_back(r->n[i]); max_tok = std::max(max_tok, r->n[i] / 960 + 2); }
+    want_logp = want_logp || r->out->logp != nullptr;
+    utts += r->batch;
+  }
+  const int V = m->cfg.vocab;
+  std::vector<int32_t> ids((size_t)utts * max_tok), tn(utts), nf(utts), fr(utts);
+  std::vector<float> logp;
+  if (want_logp) logp.resize((size_t)utts * max_tok * V);
+  pfhip_out all{};
+  all.token_ids = ids.data(); all.token_num = tn.data(); all.n_fires = nf.data(); all.n_frames = fr.data();
+  all.logp = want_logp ? logp.data() : nullptr; all.max_tokens = max_tok;
+  pfhip_status st = forward_direct(m, ptrs.data(), lens.data(), utts, nullptr, 0, &all);
+  const std::string err = g_err;
+  int u0 = 0;
+  for (BatchReq* r : take) {
+    r->st = st; r->err = err;
+    for (int i = 0; i < r->batch && st == PFHIP_OK; ++i) {
+      const int u = u0 + i;
+      if (r->out->token_num) r->out->token_num[i] = tn[u];
+      if (r->out->n_fires) r->out->n_fires[i] = nf[u];
+      if (r->out->n_frames) r->out->n_frames[i] = fr[u];
+      if ((r->out->token_ids || r->out->logp) && r->out->max_tokens < nf[u]) {
+        r->st = PFHIP_ERR_CAPACITY; r->err = "max_tokens smaller than the longest token sequence"; break;
+      }
+      if (r->out->token_ids) std::memcpy(r->out->token_ids + (size_t)i * r->out->max_tokens, ids.data() + (size_t)u * max_tok, 4 * (size_t)nf[u]);
+      if (r->out->logp) std::memcpy(r->out->logp + (size_t)i * r->out->max_tokens * V, logp.data() + (size_t)u * max_tok * V, 4 * (size_t)nf[u] * V);
+    }
+    u0 += r->batch;
+  }
+}
 
 static pfhip_status forward_batched(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,
                                     pfhip_out* out) {
-  BatchReq me{pcm, n_samples, batch, out};
-  std::unique_lock<std::mutex> ql(m->qmu);
-  m->queue.push_back(&me);
-  m->qcv.notify_all();
-  while (!me.done) {
-    if (!m->leader_active && m->queue.front() == &me) {
-      m->leader_active = true;
+  BatchReq me;
+  me.pcm = pcm; me.n = n_samples; me.batch = batch; me.out = out;
+  int wait_us, max_utts;
+  { std::lock_guard<std::mutex> l(m->bq.mu); wait_us = m->batch_wait_us; max_utts = m->batch_max_utts; }
+  m->bq.submit(
+      me, wait_us,
       // gather: wait for co-arriving requests, bounded by time and by utterance count
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(m->batch_wait_us);
-      auto queued = [&]() { int u = 0; for (BatchReq* r : m->queue) u += r->batch; return u; };
-      while (queued() < m->batch_max_utts && m->qcv.wait_until(ql, deadline) != std::cv_status::timeout) {}
-      std::vector<BatchReq*> take;
-      int utts = 0;
-      while (!m->queue.empty() && (take.empty() || utts + m->queue.front()->batch <= m->batch_max_utts)) {
-        utts += m->queue.front()->batch;
-        take.push_back(m->queue.front());
-        m->queue.pop_front();
-      }
-      ql.unlock();
-      // one packed forward for everybody
-      std::vector<const float*> ptrs; std::vector<int> lens;
-      bool want_logp = false; int max_tok = 1;
-      for (BatchReq* r : take) {
-        for (int i = 0; i < r->batch; ++i) { ptrs.push_back(r->pcm[i]); lens.push_back(r->n[i]); max_tok = std::max(max_tok, r->n[i] / 960 + 2); }
-        want_logp = want_logp || r->out->logp != nullptr;
-      }
-      const int V = m->cfg.vocab;
-      std::vector<int32_t> ids((size_t)utts * max_tok), tn(utts), nf(utts), fr(utts);
-      std::vector<float> logp;
-      if (want_logp) logp.resize((size_t)utts * max_tok * V);
-      pfhip_out all{};
-      all.token_ids = ids.data(); all.token_num = tn.data(); all.n_fires = nf.data(); all.n_frames = fr.data();
-      all.logp = want_logp ? logp.data() : nullptr; all.max_tokens = max_tok;
-      pfhip_status st = forward_direct(m, ptrs.data(), lens.data(), utts, nullptr, 0, &all);
-      const std::string err = g_err;
-      int u0 = 0;
-      for (BatchReq* r : take) {
-        r->st = st; r->err = err;
-        for (int i = 0; i < r->batch && st == PFHIP_OK; ++i) {
-          const int u = u0 + i;
-          if (r->out->token_num) r->out->token_num[i] = tn[u];
-          if (r->out->n_fires) r->out->n_fires[i] = nf[u];
-          if (r->out->n_frames) r->out->n_frames[i] = fr[u];
-          if ((r->out->token_ids || r->out->logp) && r->out->max_tokens < nf[u]) {
-            r->st = PFHIP_ERR_CAPACITY; r->err = "max_tokens smaller than the longest token sequence"; break;
-          }
-          if (r->out->token_ids) std::memcpy(r->out->token_ids + (size_t)i * r->out->max_tokens, ids.data() + (size_t)u * max_tok, 4 * (size_t)nf[u]);
-          if (r->out->logp) std::memcpy(r->out->logp + (size_t)i * r->out->max_tokens * V, logp.data() + (size_t)u * max_tok * V, 4 * (size_t)nf[u] * V);
+      [&](const std::deque<BatchReq*>& q) { int u = 0; for (BatchReq* r : q) u += r->batch; return u >= max_utts; },
+      [&](std::deque<BatchReq*>& q, std::vector<BatchReq*>& take) {
+        int utts = 0;
+        while (!q.empty() && (take.empty() || utts + q.front()->batch <= max_utts)) {
+          utts += q.front()->batch;
+          take.push_back(q.front());
+          q.pop_front();
         }
-        u0 += r->batch;
-      }
-      ql.lock();
-      for (BatchReq* r : take) r->done = true;
-      m->leader_active = false;
-      m->qcv.notify_all();
-    } else {
-      m->qcv.wait(ql);
-    }
-  }
-  ql.unlock();
+      },
+      [&](std::vector<BatchReq*>& take) { run_batch_requests(m, take); });
   if (me.st != PFHIP_OK) g_err = me.err;
   return me.st;
 }
@@ -892,7 +885,7 @@ pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, cons
 pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances) {
   g_err.clear();
   if (!m || wait_us < 0 || max_utterances < 1) return fail(PFHIP_ERR_ARG, "bad argument");
-  std::lock_guard<std::mutex> ql(m->qmu);
+  std::lock_guard<std::mutex> ql(m->bq.mu);
   m->batch_wait_us = wait_us;
   m->batch_max_utts = max_utterances;
   return PFHIP_OK;

@@ -499,6 +499,7 @@ pfhip_status pfhip_stream_create(pfhip_model* m, const int* chunk_size, pfhip_st
   st = init_cache(s.get(), m->own_stream);
   if (st) return st;
   HIP_TRY(hipStreamSynchronize(m->own_stream));
+  ++m->live_streams;
   *out = s.release();
   return PFHIP_OK;
 }
@@ -512,6 +513,7 @@ void pfhip_stream_destroy(pfhip_stream* s) {
     for (Buf* b : {&s->fb[0], &s->fb[1], &s->rows, &s->featc, &s->chunk, &s->carry, &s->dcache})
       b->release();
   }
+  --s->m->live_streams;
   delete s;
 }
 
@@ -653,57 +655,44 @@ pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_stre
 // (websocket-server-2pass.cpp:266-297).  With pfhip_set_stream_batching(wait_us > 0) concurrent pfhip_stream_forward callers on
 // streams of one model are merged like the offline callers (pfhip_set_batching): the first to arrive leads, waits up to
 // wait_us for others, runs ONE batched forward (forward_calls) and hands every caller its ids.
-struct StreamReq {
+struct StreamReq : pfhip_detail::MergeReqBase {
   pfhip_stream* s; const float* pcm; int n; int fin; int32_t* ids; int cap; int* n_out;
-  pfhip_status st = PFHIP_OK; std::string err; bool done = false;
+  pfhip_status st = PFHIP_OK; std::string err;
 };
 
 namespace {
 
-pfhip_status run_requests(pfhip_model* m, const std::vector<StreamReq*>& reqs) {
+void run_requests(const std::vector<StreamReq*>& reqs) {
   const int n = (int)reqs.size();
   std::vector<pfhip_stream*> ss(n);
   std::vector<const float*> pcm(n);
   std::vector<int> ns(n), fin(n), cap(n), nt(n);
   std::vector<int32_t*> ids(n);
   for (int i = 0; i < n; ++i) { ss[i] = reqs[i]->s; pcm[i] = reqs[i]->pcm; ns[i] = reqs[i]->n; fin[i] = reqs[i]->fin; ids[i] = reqs[i]->ids; cap[i] = reqs[i]->cap; }
-  (void)m;
   const pfhip_status st = pfhip_stream_forward_batch(ss.data(), n, pcm.data(), ns.data(), fin.data(), ids.data(), cap.data(), nt.data());
-  for (int i = 0; i < n; ++i) *reqs[i]->n_out = nt[i];
-  return st;
+  const std::string err = pfhip_detail::last_error();
+  for (int i = 0; i < n; ++i) { *reqs[i]->n_out = nt[i]; reqs[i]->st = st; reqs[i]->err = err; }
 }
 
 pfhip_status stream_forward_queued(pfhip_model* m, StreamReq& me) {
-  std::unique_lock<std::mutex> ql(m->sq_mu);
-  m->squeue.push_back(&me);
-  m->sq_cv.notify_all();
-  while (!me.done) {
-    if (!m->sq_leader_active && m->squeue.front() == &me) {
-      m->sq_leader_active = true;
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(m->stream_wait_us);
-      while ((int)m->squeue.size() < m->stream_max && m->sq_cv.wait_until(ql, deadline) != std::cv_status::timeout) {}
-      std::vector<StreamReq*> take;
-      std::deque<StreamReq*> later;
-      while (!m->squeue.empty() && (int)take.size() < m->stream_max) {
-        StreamReq* r = m->squeue.front();
-        m->squeue.pop_front();
-        bool dup = false;                       // two queued calls on ONE stream must stay in order: the second waits
-        for (StreamReq* t : take) dup = dup || t->s == r->s;
-        if (dup) later.push_back(r); else take.push_back(r);
-      }
-      for (auto it = later.rbegin(); it != later.rend(); ++it) m->squeue.push_front(*it);
-      ql.unlock();
-      const pfhip_status st = run_requests(m, take);
-      const std::string err = pfhip_detail::last_error();
-      ql.lock();
-      for (StreamReq* r : take) { r->st = st; r->err = err; r->done = true; }
-      m->sq_leader_active = false;
-      m->sq_cv.notify_all();
-    } else {
-      m->sq_cv.wait(ql);
-    }
-  }
-  ql.unlock();
+  int wait_us, cap;
+  { std::lock_guard<std::mutex> l(m->sq.mu); wait_us = m->stream_wait_us; cap = m->stream_max; }
+  m->sq.submit(
+      me, wait_us,
+      // wait for company: until every open stream has a call queued (connections advancing together), the cap, or the deadline
+      [&](const std::deque<StreamReq*>& q) { return (int)q.size() >= std::min(cap, std::max(1, m->live_streams.load())); },
+      [&](std::deque<StreamReq*>& q, std::vector<StreamReq*>& take) {
+        std::deque<StreamReq*> later;
+        while (!q.empty() && (int)take.size() < cap) {
+          StreamReq* r = q.front();
+          q.pop_front();
+          bool dup = false;                       // two queued calls on ONE stream must stay in order: the second waits
+          for (StreamReq* t : take) dup = dup || t->s == r->s;
+          if (dup) later.push_back(r); else take.push_back(r);
+        }
+        for (auto it = later.rbegin(); it != later.rend(); ++it) q.push_front(*it);
+      },
+      [&](std::vector<StreamReq*>& take) { run_requests(take); });
   if (me.st != PFHIP_OK) pfhip_detail::last_error() = me.err;
   return me.st;
 }
@@ -715,7 +704,7 @@ extern "C" {
 pfhip_status pfhip_set_stream_batching(pfhip_model* m, int wait_us, int max_streams) {
   last_error().clear();
   if (!m || wait_us < 0 || max_streams < 1) return fail(PFHIP_ERR_ARG, "bad argument");
-  std::lock_guard<std::mutex> ql(m->sq_mu);
+  std::lock_guard<std::mutex> ql(m->sq.mu);
   m->stream_wait_us = wait_us;
   m->stream_max = max_streams;
   return PFHIP_OK;
@@ -727,7 +716,8 @@ pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_sampl
   if (s->m->stream_wait_us > 0 && !s->debug) {
     last_error().clear();
     if (n_samples < 0 || (n_samples > 0 && !pcm) || n_samples > kMaxSamples) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
-    StreamReq me{s, pcm, n_samples, input_finished, token_ids, cap, n_tokens};
+    StreamReq me;
+    me.s = s; me.pcm = pcm; me.n = n_samples; me.fin = input_finished; me.ids = token_ids; me.cap = cap; me.n_out = n_tokens;
     *n_tokens = 0;
     return stream_forward_queued(s->m, me);
   }

@@ -5,6 +5,7 @@
 // onnxruntime/src/audio.cpp:1183-1196); slice-wise calls give the same scores because the caches carry over.
 // Linear layers run on the same fp32 MFMA GEMM kernels as the ASR model; their odd widths (140, 250, 248) are
 // zero-padded once at load ([N up to 128][K up to 32]) so that pad outputs are exact zeros.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -31,8 +32,9 @@ struct pfhip_vad {
   // pinned staging for the online path's PCM (grown on demand); h_wave(n) returns a buffer of at least n floats
   float* h_wave_buf = nullptr; size_t h_wave_cap = 0;
   // merging of concurrent pfhip_vad_stream_infer callers (pfhip_set_vad_stream_batching)
-  std::mutex q_mu; std::condition_variable q_cv; std::deque<struct VadReq*> queue; bool q_leader_active = false;
+  pfhip_detail::MergeQueue<struct VadReq> mq;
   int q_wait_us = 0, q_max = 1;
+  std::atomic<int> live_streams{0};
   float* h_wave(size_t n) {
     if (n > h_wave_cap) {
       if (h_wave_buf) (void)hipHostFree(h_wave_buf);
@@ -302,6 +304,7 @@ pfhip_status pfhip_vad_stream_create(pfhip_vad* v, pfhip_vad_stream** out) {
   pfhip_status st = vs_zero_caches(vs.get(), v->stream);
   if (st) return st;
   HIP_TRY(hipStreamSynchronize(v->stream));
+  ++v->live_streams;
   *out = vs.release();
   return PFHIP_OK;
 }
@@ -314,6 +317,7 @@ void pfhip_vad_stream_destroy(pfhip_vad_stream* vs) {
     (void)hipStreamSynchronize(vs->v->stream);
     for (Buf* b : {&vs->fb[0], &vs->fb[1], &vs->cache[0], &vs->cache[1]}) b->release();
   }
+  --vs->v->live_streams;
   delete vs;
 }
 
@@ -562,7 +566,7 @@ pfhip_status pfhip_vad_stream_infer_batch(pfhip_vad_stream* const* streams, int 
 pfhip_status pfhip_set_vad_stream_batching(pfhip_vad* v, int wait_us, int max_streams) {
   last_error().clear();
   if (!v || wait_us < 0 || max_streams < 1) return fail(PFHIP_ERR_ARG, "bad argument");
-  std::lock_guard<std::mutex> ql(v->q_mu);
+  std::lock_guard<std::mutex> ql(v->mq.mu);
   v->q_wait_us = wait_us;
   v->q_max = max_streams;
   return PFHIP_OK;
@@ -572,14 +576,14 @@ pfhip_status pfhip_set_vad_stream_batching(pfhip_vad* v, int wait_us, int max_st
 
 // One FsmnVadOnline::Infer per websocket handler thread (funasrruntime.cpp:516-532): with wait_us > 0 the first caller to
 // arrive leads, waits up to wait_us for the others and runs ONE pfhip_vad_stream_infer_batch for all of them.
-struct VadReq {
+struct VadReq : pfhip_detail::MergeReqBase {
   pfhip_vad_stream* vs; const float* pcm; int n; int fin; float* sil; size_t cap; int* nf; float* wo; size_t wcap; int* nw;
-  pfhip_status st = PFHIP_OK; std::string err; bool done = false;
+  pfhip_status st = PFHIP_OK; std::string err;
 };
 
 namespace {
 
-pfhip_status vad_run_requests(const std::vector<VadReq*>& reqs) {
+void vad_run_requests(const std::vector<VadReq*>& reqs) {
   const int n = (int)reqs.size();
   std::vector<pfhip_vad_stream*> ss(n);
   std::vector<const float*> pcm(n);
@@ -592,41 +596,28 @@ pfhip_status vad_run_requests(const std::vector<VadReq*>& reqs) {
   }
   const pfhip_status st = pfhip_vad_stream_infer_batch(ss.data(), n, pcm.data(), ns.data(), fin.data(), sil.data(), cap.data(),
                                                        nf.data(), wo.data(), wcap.data(), nw.data());
-  for (int i = 0; i < n; ++i) { *reqs[i]->nf = nf[i]; *reqs[i]->nw = nw[i]; }
-  return st;
+  const std::string err = pfhip_detail::last_error();
+  for (int i = 0; i < n; ++i) { *reqs[i]->nf = nf[i]; *reqs[i]->nw = nw[i]; reqs[i]->st = st; reqs[i]->err = err; }
 }
 
 pfhip_status vad_infer_queued(pfhip_vad* v, VadReq& me) {
-  std::unique_lock<std::mutex> ql(v->q_mu);
-  v->queue.push_back(&me);
-  v->q_cv.notify_all();
-  while (!me.done) {
-    if (!v->q_leader_active && v->queue.front() == &me) {
-      v->q_leader_active = true;
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(v->q_wait_us);
-      while ((int)v->queue.size() < v->q_max && v->q_cv.wait_until(ql, deadline) != std::cv_status::timeout) {}
-      std::vector<VadReq*> take;
-      std::deque<VadReq*> later;
-      while (!v->queue.empty() && (int)take.size() < v->q_max) {
-        VadReq* r = v->queue.front();
-        v->queue.pop_front();
-        bool dup = false;                       // two queued calls on ONE connection stay in order: the second waits
-        for (VadReq* t : take) dup = dup || t->vs == r->vs;
-        if (dup) later.push_back(r); else take.push_back(r);
-      }
-      for (auto it = later.rbegin(); it != later.rend(); ++it) v->queue.push_front(*it);
-      ql.unlock();
-      const pfhip_status st = vad_run_requests(take);
-      const std::string err = pfhip_detail::last_error();
-      ql.lock();
-      for (VadReq* r : take) { r->st = st; r->err = err; r->done = true; }
-      v->q_leader_active = false;
-      v->q_cv.notify_all();
-    } else {
-      v->q_cv.wait(ql);
-    }
-  }
-  ql.unlock();
+  int wait_us, cap;
+  { std::lock_guard<std::mutex> l(v->mq.mu); wait_us = v->q_wait_us; cap = v->q_max; }
+  v->mq.submit(
+      me, wait_us,
+      [&](const std::deque<VadReq*>& q) { return (int)q.size() >= std::min(cap, std::max(1, v->live_streams.load())); },
+      [&](std::deque<VadReq*>& q, std::vector<VadReq*>& take) {
+        std::deque<VadReq*> later;
+        while (!q.empty() && (int)take.size() < cap) {
+          VadReq* r = q.front();
+          q.pop_front();
+          bool dup = false;                       // two queued calls on ONE connection stay in order: the second waits
+          for (VadReq* t : take) dup = dup || t->vs == r->vs;
+          if (dup) later.push_back(r); else take.push_back(r);
+        }
+        for (auto it = later.rbegin(); it != later.rend(); ++it) q.push_front(*it);
+      },
+      [&](std::vector<VadReq*>& take) { vad_run_requests(take); });
   if (me.st != PFHIP_OK) pfhip_detail::last_error() = me.err;
   return me.st;
 }
@@ -640,9 +631,11 @@ pfhip_status pfhip_vad_stream_infer(pfhip_vad_stream* vs, const float* pcm, int 
   if (!vs || !n_frames || !n_waves) { last_error().clear(); return fail(PFHIP_ERR_ARG, "bad argument"); }
   pfhip_vad* v = vs->v;
   bool queued;
-  { std::lock_guard<std::mutex> ql(v->q_mu); queued = v->q_wait_us > 0 && v->q_max > 1; }
+  { std::lock_guard<std::mutex> ql(v->mq.mu); queued = v->q_wait_us > 0 && v->q_max > 1; }
   if (queued) {
-    VadReq me{vs, pcm, n_samples, input_finished, sil_prob, cap_floats, n_frames, waves_out, waves_cap, n_waves};
+    VadReq me;
+    me.vs = vs; me.pcm = pcm; me.n = n_samples; me.fin = input_finished; me.sil = sil_prob; me.cap = cap_floats; me.nf = n_frames;
+    me.wo = waves_out; me.wcap = waves_cap; me.nw = n_waves;
     return vad_infer_queued(v, me);
   }
   const float* p[1] = {pcm};

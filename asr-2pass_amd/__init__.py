@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "pfhip_vad_stream_infer", "pfhip_vad_stream_infer_batch", "pfhip_set_vad_stream_batching", "pfhip_vadseg_create", "pfhip_vadseg_destroy", "pfhip_vadseg_reset", "pfhip_vadseg_feed",
     "pfhip_timestamp_onnx", "pfhip_post_process",
     "pfhip_punc_create_from_memory", "pfhip_punc_destroy", "pfhip_punc_num_classes", "pfhip_punc_infer",
-    "pfhip_punc_infer_online", "pfhip_punc_add_punc",
+    "pfhip_punc_infer_online", "pfhip_punc_infer_batch", "pfhip_set_punc_batching", "pfhip_punc_add_punc",
 ]
 
 
@@ -131,6 +131,8 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_punc_infer.argtypes = [vp, vp, ci, vp, vp]
     lib.pfhip_punc_infer_online.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.pfhip_punc_add_punc.argtypes = [vp, vp, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.pfhip_punc_infer_batch.argtypes = [vp, vp, vp, vp, ci, vp]
+    lib.pfhip_set_punc_batching.argtypes = [vp, ci, ci]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -539,6 +541,22 @@ class CTTransformerHip:
         else:
             _check(self._lib, self._lib.pfhip_punc_infer_online(self._h, ids.ctypes.data, n, int(nCacheSize), punc.ctypes.data, lp))
         return (punc, logits) if want_logits else punc
+
+    def InferBatch(self, sequences, nCacheSizes=None):
+        """Several Infer calls as one packed device pass (pfhip_punc_infer_batch); nCacheSizes: per sequence, realtime model."""
+        seqs = [np.ascontiguousarray(x, dtype=np.int32) for x in sequences]
+        B = len(seqs)
+        outs = [np.zeros(x.size, np.int32) for x in seqs]
+        P = ctypes.c_void_p * B
+        pi = P(*[x.ctypes.data for x in seqs])
+        po = P(*[x.ctypes.data for x in outs])
+        ns = (ctypes.c_int * B)(*[int(x.size) for x in seqs])
+        cs = (ctypes.c_int * B)(*[int(c) for c in nCacheSizes]) if nCacheSizes is not None else None
+        _check(self._lib, self._lib.pfhip_punc_infer_batch(self._h, pi, ns, cs, B, po))
+        return outs
+
+    def set_batching(self, wait_us, max_sequences):
+        _check(self._lib, self._lib.pfhip_set_punc_batching(self._h, int(wait_us), int(max_sequences)))
 
 
 class FsmnVadOnlineHip:

@@ -253,6 +253,8 @@ PuncModelHipBase* CreatePuncModelHip(const std::string& punc_dir, int thread_num
   }
   CTTransformerHip* m = allow_online && punc_dir.find("realtime") != std::string::npos ? new CTTransformerOnlineHip() : new CTTransformerHip();
   m->InitPunc(blob, man, tok, thread_num);
+  // one AddPunc per handler thread, each a few Infer calls: merged into packed device passes
+  if (thread_num > 1) pfhip_set_punc_batching(m->Handle(), 300, 128);
   return m;
 }
 

@@ -61,6 +61,7 @@ class CTTransformerHip : public PuncModelHipBase {
   std::string AddPunc(const char* sz_input, std::string language = "zh-cn") override;
   std::string AddPunc(const char* sz_input, std::vector<std::string>& arr_cache, std::string language = "zh-cn") override;
   void SetDevice(int device) { device_ = device; }
+  pfhip_punc* Handle() const { return handle_; }
 
  protected:
   std::vector<int> Infer(const std::vector<int32_t>& ids, int cache_size) const;

@@ -22,7 +22,6 @@ struct OfflineStreamHip {
   std::unique_ptr<funasr::FsmnVadHip> vad;
   std::mutex vad_mu;            // FsmnVad keeps per-file caches: one file at a time, like the reference's per-call Reset
   std::unique_ptr<funasr::PuncModelHipBase> punc;      // OfflineStream::punc_handle (offline-stream.cpp:105-129)
-  std::mutex punc_mu;
 };
 
 struct RecogResult {               // funasr::FUNASR_RECOG_RESULT (com-define.h)
@@ -180,10 +179,7 @@ FUNASR_RESULT FunOfflineInferBuffer(FUNASR_HANDLE handle, const char* sz_buf, in
     cur_stamp.erase(cur_stamp.size() - 1);
     res->stamp = cur_stamp + "]";
   }
-  if (os->punc) {                                                                      // funasrruntime.cpp:317-320
-    std::lock_guard<std::mutex> lk(os->punc_mu);
-    res->msg = os->punc->AddPunc(res->msg.c_str(), "zh-cn");
-  }
+  if (os->punc) res->msg = os->punc->AddPunc(res->msg.c_str(), "zh-cn");               // funasrruntime.cpp:317-320 (re-entrant)
   return res.release();
 }
 
@@ -213,7 +209,6 @@ struct TpassStreamHip {               // funasr::TpassStream (tpass-stream.cpp):
   funasr::ParaformerHip asr, asr_online;
   funasr::FsmnVadHip vad;
   std::unique_ptr<funasr::PuncModelHipBase> punc_online;      // TpassStream::punc_online_handle (tpass-stream.cpp:100-135)
-  std::mutex punc_mu;
 };
 
 struct TpassOnlineStreamHip {         // funasr::TpassOnlineStream (tpass-online-stream.cpp:14-15): per connection
@@ -300,10 +295,7 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
       os->online_res += msg;
       if (frame.is_final) {                                                         // funasrruntime.cpp:543-556
         res->tpass_msg = os->online_res;
-        if (ts->punc_online) {
-          std::lock_guard<std::mutex> lk(ts->punc_mu);
-          res->tpass_msg = ts->punc_online->AddPunc(os->online_res.c_str(), punc_cache[0]);
-        }
+        if (ts->punc_online) res->tpass_msg = ts->punc_online->AddPunc(os->online_res.c_str(), punc_cache[0]);
         os->online_res.clear();
       }
       res->msg += msg;
@@ -335,8 +327,7 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
       res->stamp += cur_stamp + "]";
     }
     res->tpass_msg = msg;
-    if (ts->punc_online) {                                                          // funasrruntime.cpp:609-614
-      std::lock_guard<std::mutex> lk(ts->punc_mu);
+    if (ts->punc_online) {                                                          // funasrruntime.cpp:609-614 (re-entrant)
       res->tpass_msg = ts->punc_online->AddPunc(msg.c_str(), punc_cache[1]);
       if (input_finished && ts->punc_online->is_online) res->tpass_msg += "\xE3\x80\x82";      // "。"
     }

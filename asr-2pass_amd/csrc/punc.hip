@@ -9,12 +9,13 @@ namespace {
 __global__ __launch_bounds__(128) void embed_gather_kernel(const int32_t* __restrict__ ids,
                                                            const float* __restrict__ table, int vocab, int D,
                                                            float* __restrict__ out, int ldo, int N,
-                                                           const float* __restrict__ inv_ts, float scale) {
+                                                           const float* __restrict__ inv_ts, float scale,
+                                                           const int* __restrict__ pos_of_row) {
   const int row = blockIdx.x;
   if (row >= N) return;
   int id = ids[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  const float pos = (float)(row + 1);
+  const float pos = (float)((pos_of_row ? pos_of_row[row] : row) + 1);      // position inside its own sequence
   const int half = D >> 1;
   for (int c = threadIdx.x; c < D; c += blockDim.x) {
     const int i = c < half ? c : c - half;
@@ -37,9 +38,9 @@ __global__ __launch_bounds__(256) void argmax_first_kernel(const float* __restri
 }  // namespace
 
 void launch_embed_gather(const int32_t* ids, const float* table, int vocab, int D, float* out, int ldo, int N,
-                         const float* inv_ts, float scale, hipStream_t s) {
+                         const float* inv_ts, float scale, const int* pos_of_row, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(embed_gather_kernel, dim3(N), dim3(128), 0, s, ids, table, vocab, D, out, ldo, N, inv_ts, scale);
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(N), dim3(128), 0, s, ids, table, vocab, D, out, ldo, N, inv_ts, scale, pos_of_row);
 }
 void launch_argmax_first(const float* logits, int ldl, int N, int ncls, int32_t* out, hipStream_t s) {
   if (N <= 0) return;

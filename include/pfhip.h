@@ -258,6 +258,13 @@ pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t*
  * look-ahead is the container's `sanm_shift` (0 or 5). */
 pfhip_status pfhip_punc_infer_online(pfhip_punc* p, const int32_t* ids, int n, int cache_size, int32_t* punc_out,
                                      float* logits_out);
+/* n_seq sequences in one packed device pass (positions, FSMN memory and attention per sequence): results identical to n_seq
+ * separate pfhip_punc_infer calls (cache_size == NULL) / pfhip_punc_infer_online calls (cache_size[b] per sequence).
+ * pfhip_set_punc_batching(wait_us > 0, max_sequences > 1) merges concurrent single-sequence callers (one AddPunc per handler
+ * thread) into such passes; offline and realtime calls are never mixed in one pass.  Default: off. */
+pfhip_status pfhip_punc_infer_batch(pfhip_punc* p, const int32_t* const* ids, const int* n, const int* cache_size, int n_seq,
+                                    int32_t* const* punc_out);
+pfhip_status pfhip_set_punc_batching(pfhip_punc* p, int wait_us, int max_sequences);
 /* AddPunc's mini-sentence loop on token ids (ct-transformer.cpp:39-155): 20-token mini-sentences, the tail after the last
  * sentence end carried into the next Infer, forced period at the last comma beyond CACHE_POP_TRIGGER_LIMIT carried tokens,
  * sentence-final fix-up.  punc_out receives one punctuation id per token and, when the text does not end in "。"/"？", one

@@ -97,3 +97,41 @@ def test_add_punc_mini_sentences(pkg, weights_mod):
             assert list(got) == ref, (bias, n)
             assert len(ref) in (n, n + 1) and ref[-1] in (3, 4)
         h.close()
+
+
+def test_batched_infer_equals_separate_calls(punc):
+    """pfhip_punc_infer_batch packs sequences of different lengths (1 .. 220 tokens) into one pass: every sequence gets exactly
+    the punctuation a call of its own gets — offline and with per-sequence realtime masks."""
+    h, W = punc
+    rng = np.random.default_rng(99)
+    lens = [1, 20, 33, 7, 64, 129, 220, 2, 40]
+    seqs = [rng.integers(0, 5000, n).astype(np.int32) for n in lens]
+    got = h.InferBatch(seqs)
+    for x, g in zip(seqs, got):
+        assert np.array_equal(g, h.Infer(x))
+    caches = [0, 3, 40, 2, 10, 128, 1, 5, 39]
+    got = h.InferBatch(seqs, caches)
+    for x, c, g in zip(seqs, caches, got):
+        assert np.array_equal(g, h.Infer(x, nCacheSize=c))
+
+
+def test_concurrent_infer_callers_are_merged(punc):
+    import threading
+    h, W = punc
+    rng = np.random.default_rng(100)
+    seqs = [rng.integers(0, 5000, 10 + 7 * i).astype(np.int32) for i in range(12)]
+    want = [h.Infer(x) for x in seqs]
+    want_on = [h.Infer(x, nCacheSize=4) for x in seqs]
+    h.set_batching(2000, 16)
+    got, got_on = [None] * 12, [None] * 12
+
+    def run(i):
+        got[i] = h.Infer(seqs[i])
+        got_on[i] = h.Infer(seqs[i], nCacheSize=4)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(12)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    h.set_batching(0, 1)
+    for i in range(12):
+        assert np.array_equal(got[i], want[i]) and np.array_equal(got_on[i], want_on[i])

@@ -21,6 +21,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace pfhip {
 namespace {
@@ -712,6 +713,15 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
                           hipStream_t s) {
   if (M <= 0 || N <= 0) return;
   const int tiles = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
+  // Large launches go to the BF16 matrix cores (three-way split, six MFMAs per block: gemm_x6.hip) — 1.45-1.5 x the fp32 MFMA
+  // kernel on the encoder shapes, results at least as close to fp64 as the fp32 chain.  PFHIP_GEMM_X6=0 turns it off.
+  static const bool x6_on = [] { const char* e = getenv("PFHIP_GEMM_X6"); return !(e && e[0] == '0'); }();
+  const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
+  if (kind == 4 || (kind == 0 && x6_on && M >= 2048 && tiles256 >= 128)) {
+    launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
+                           column_group_width(M, K, (N + kTileN - 1) / kTileN), s);
+    return;
+  }
   const bool skinny = kind == 2 || (kind == 0 && tiles < kStreamingBelowTiles);
   const bool half = kind == 3 || (kind == 0 && prefer_half_tile(tiles));
   if (skinny) {   // always bounds-checked

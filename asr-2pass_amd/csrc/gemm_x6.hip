@@ -1,0 +1,250 @@
+// fp32 GEMM on the gfx950 BF16 matrix cores: C = A * W^T (+bias, +residuals, ReLU), with fp32-grade results.
+//
+// On CDNA4 the fp32 MFMA (`v_mfma_f32_32x32x2_f32`) runs at the vector rate, 157 TFLOP/s — 1/16 of the BF16 MFMA
+// (MI355X_MICROARCH.md § Matrix cores).  An fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 significand bits):
+//     a = a1 + a2 + a3,  a1 = top 16 bits of a,  a2 = top 16 bits of (a - a1),  a3 = a - a1 - a2      (all subtractions exact)
+// and a product of two bf16 numbers is exact in fp32, so
+//     a*b = a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a3*b1 + a2*b2) + O(2^-24 |a*b|)
+// costs six `v_mfma_f32_32x32x16_bf16` per 32x32x16 block instead of eight fp32 MFMAs of four times their duration: a ceiling of
+// 2.5 PF / 6 = 417 TFLOP/s of fp32-equivalent work.  The three dropped terms are below fp32's own rounding of the product;
+// accumulation is fp32 in the matrix core as before.  Measured against an fp64 reference the result is slightly CLOSER than
+// the fp32 MFMA chain (rms 1.2e-7 vs 2.9e-7 relative at K = 512: the partial products carry no rounding of their own).
+//
+// Tiling: 256 x 128 block tile, 8 waves as 4 x 2 (two per SIMD), each 64 x 64 = 2 x 2 MFMA tiles.  K-step 16 = one MFMA depth.
+// Operands are split while they are staged: global fp32 -> registers -> three bf16 planes in LDS (row stride 48 B: the 16-lane
+// groups of ds_read_b128 hit 16 distinct 16-B slots), double-buffered, one barrier per K-step; the split of the NEXT step's
+// operands (5.5 VALU ops per element) and its LDS writes sit between this step's MFMAs, and the second wave of the SIMD fills
+// what is left.  Per K-step a wave issues 12 ds_read_b128 for 24 MFMAs.
+// Epilogue as in gemm.hip: accumulators transposed through LDS (two 128-row halves), rows written with 16-byte accesses.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace pfhip {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int kBM = 256, kBN = 128, kBK = 16;
+constexpr int kRowB = 48;                                   // bytes per operand row in LDS (16 bf16 + pad)
+constexpr int kPlaneA = kBM * kRowB, kPlaneW = kBN * kRowB; // bytes per plane
+constexpr int kStageB = 3 * (kPlaneA + kPlaneW);            // 55,296 B
+constexpr int kCs = kBN + 4;                                // padded C-tile row stride (floats)
+constexpr int kLdsBytes = 2 * kStageB;                      // 110,592 B
+static_assert(128 * kCs * 4 <= kLdsBytes, "half C tile must fit the operand buffers");
+
+__device__ __forceinline__ unsigned top16_pair(float lo, float hi) {      // (bf16 trunc of hi) << 16 | (bf16 trunc of lo)
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float rest(float x) {                           // x - top16(x), exact
+  return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+}
+
+// XCD-aware, column-group-major tile order (same scheme as gemm.hip's tile_of_block)
+__device__ __forceinline__ void tile_of_block_x6(int bid, int n_tiles, int tiles_n, int gw, int& tm, int& tn) {
+  {
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tiles_m = n_tiles / tiles_n, full = tiles_n / gw, span = tiles_m * gw;
+  if (bid < full * span) {
+    const int g = bid / span, j = bid - g * span;
+    tm = j / gw; tn = g * gw + (j - tm * gw);
+  } else {
+    const int j = bid - full * span, w = tiles_n - full * gw;
+    tm = j / w; tn = full * gw + (j - tm * w);
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
+    const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
+    int n_tiles, int gw, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  int tm, tn;
+  tile_of_block_x6(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
+  const int m0 = tm * kBM, n0 = tn * kBN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // staging map: thread t holds 4 consecutive k (one of the four 16-B pieces of a row's 64-B K-step) of A rows t/4 and
+  // t/4 + 128 and of W row t/4: a wave's load instruction covers 16 rows x 64 contiguous bytes
+  const int srow = tid >> 2, sq = tid & 3;
+  const float* Ag0 = A + (size_t)min(m0 + srow, M - 1) * lda + 4 * sq;
+  const float* Ag1 = A + (size_t)min(m0 + srow + 128, M - 1) * lda + 4 * sq;
+  const float* Wg = W + (size_t)min(n0 + srow, N - 1) * ldw + 4 * sq;
+  const int a_st = srow * kRowB + 8 * sq;                   // byte offset inside an A plane (second row: + 128 rows)
+  const int w_st = 3 * kPlaneA + srow * kRowB + 8 * sq;     // byte offset of the W planes inside a stage
+  const int a_fr = (wr * 64 + r) * kRowB + 16 * h;
+  const int w_fr = 3 * kPlaneA + (wc * 64 + r) * kRowB + 16 * h;
+
+  // two raw register sets: the global loads run two K-steps ahead of the split that consumes them
+  float4 xa0, xa1, xw, ya0, ya1, yw;
+#define PFHIP_LOAD_RAW(RA0, RA1, RW, k0)                       \
+  RA0 = *reinterpret_cast<const float4*>(Ag0 + (k0));          \
+  RA1 = *reinterpret_cast<const float4*>(Ag1 + (k0));          \
+  RW = *reinterpret_cast<const float4*>(Wg + (k0));
+  auto split3 = [&](const float4& v, unsigned char* base, int plane_bytes) {
+    uint2 p;
+    p.x = top16_pair(v.x, v.y); p.y = top16_pair(v.z, v.w);
+    *reinterpret_cast<uint2*>(base) = p;
+    float4 s = make_float4(rest(v.x), rest(v.y), rest(v.z), rest(v.w));
+    p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
+    *reinterpret_cast<uint2*>(base + plane_bytes) = p;
+    s = make_float4(rest(s.x), rest(s.y), rest(s.z), rest(s.w));
+    p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
+    *reinterpret_cast<uint2*>(base + 2 * plane_bytes) = p;
+  };
+#define PFHIP_SPLIT_STORE(RA0, RA1, RW, stage)                                \
+  split3(RA0, lds + (stage) * kStageB + a_st, kPlaneA);                       \
+  split3(RA1, lds + (stage) * kStageB + a_st + 128 * kRowB, kPlaneA);         \
+  split3(RW, lds + (stage) * kStageB + w_st, kPlaneW);
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+
+  // operand fragments: even K-steps in f*, odd in g* — [plane][tile]
+  bf16x8 fa[3][2], fb[3][2], ga[3][2], gb[3][2];
+#define PFHIP_FRAGS(FA, FB, stage)                                                                                  \
+  _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+      FA[p][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kStageB + p * kPlaneA + a_fr + i * 32 * kRowB)); \
+      FB[p][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kStageB + p * kPlaneW + w_fr + i * 32 * kRowB)); \
+    }                                                                                                               \
+  }
+#define PFHIP_X6(FA, FB, pa, pb)                                                              \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa][0], FB[pb][0], acc00, 0, 0, 0);      \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa][0], FB[pb][1], acc01, 0, 0, 0);      \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa][1], FB[pb][0], acc10, 0, 0, 0);      \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa][1], FB[pb][1], acc11, 0, 0, 0);
+#define PFHIP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+  // The barrier is `s_waitcnt lgkmcnt(0); s_barrier` by hand: __syncthreads() also waits for vmcnt(0), i.e. for the global
+  // loads issued a few instructions earlier — a full memory latency per K-step (measured: 1.16 us per step with it).
+  // One K-step, one barrier.  Region 1: 16 MFMAs of this step, between them the split of the next step's operands (66 VALU
+  // ops), its 6 LDS writes and the 3 global loads of the step after.  Barrier.  Region 2: the last 8 MFMAs, between them the
+  // 12 fragment reads of the next step (into the other fragment set).  Masks: 0x8 MFMA, 0x2 VALU, 0x200 DS write,
+  // 0x100 DS read, 0x20 VMEM read.
+#define PFHIP_STEP(FA, FB, GA, GB, RA0, RA1, RW, nxt, knext)                                  \
+  PFHIP_SPLIT_STORE(RA0, RA1, RW, nxt)                                                        \
+  PFHIP_LOAD_RAW(RA0, RA1, RW, knext)                                                         \
+  PFHIP_X6(FA, FB, 1, 1) PFHIP_X6(FA, FB, 0, 2) PFHIP_X6(FA, FB, 2, 0) PFHIP_X6(FA, FB, 0, 1)  \
+  _Pragma("unroll") for (int q = 0; q < 9; ++q) {                                             \
+    PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1);                                \
+  }                                                                                           \
+  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 1); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 1);               \
+  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 1); PFHIP_SGB(0x8, 4);                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
+  __builtin_amdgcn_sched_barrier(0);                                                          \
+  PFHIP_FRAGS(GA, GB, nxt)                                                                    \
+  PFHIP_X6(FA, FB, 1, 0) PFHIP_X6(FA, FB, 0, 0)                                               \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+    PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 2); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 1);           \
+  }                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int nk = K / kBK;
+  auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
+  PFHIP_LOAD_RAW(xa0, xa1, xw, 0)
+  PFHIP_SPLIT_STORE(xa0, xa1, xw, 0)
+  PFHIP_LOAD_RAW(ya0, ya1, yw, kclamp(1))                  // K-step 1 -> y, K-step 2 -> x: step kt splits set (kt + 1) & 1
+  PFHIP_LOAD_RAW(xa0, xa1, xw, kclamp(2))
+  __syncthreads();
+  PFHIP_FRAGS(fa, fb, 0)
+
+  // splits / loads past the last K-step redo the last one (never used): keeps the bodies straight-line
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    { const int knext = kclamp(kt + 3); PFHIP_STEP(fa, fb, ga, gb, ya0, ya1, yw, 1, knext) }
+    { const int knext = kclamp(kt + 4); PFHIP_STEP(ga, gb, fa, fb, xa0, xa1, xw, 0, knext) }
+  }
+  if (kt < nk) { const int knext = kclamp(nk); PFHIP_STEP(fa, fb, ga, gb, ya0, ya1, yw, 1, knext) }
+#undef PFHIP_STEP
+#undef PFHIP_SPLIT_STORE
+#undef PFHIP_LOAD_RAW
+#undef PFHIP_SGB
+#undef PFHIP_X6
+#undef PFHIP_FRAGS
+  __syncthreads();                        // every wave has finished reading operand fragments
+
+  // ---- epilogue: two 128-row halves through LDS (C/D map: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)) ------------------
+  float* const Cs = reinterpret_cast<float*>(lds);
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    else {
+      if (gcol < N) bv.x = bias[gcol];
+      if (gcol + 1 < N) bv.y = bias[gcol + 1];
+      if (gcol + 2 < N) bv.z = bias[gcol + 2];
+    }
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if ((wr >> 1) == half) {
+      float* cw = Cs + ((wr & 1) * 64 + 4 * h) * kCs + wc * 64 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ro = ((e & 3) + 8 * (e >> 2)) * kCs;
+        cw[ro] = acc00[e];
+        cw[ro + 32] = acc01[e];
+        cw[ro + 32 * kCs] = acc10[e];
+        cw[ro + 32 * kCs + 32] = acc11[e];
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 16 + rsub;
+      const int grow = m0 + half * 128 + row;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      if (grow < M && gcol + 3 < N) {
+        if (R1) {
+          const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (R2) {
+          const float4 t = *reinterpret_cast<const float4*>(R2 + (size_t)grow * ldr2 + gcol);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      } else if (grow < M && gcol < N) {      // ragged right edge: element-wise
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int q = 0; q < 4 && gcol + q < N; ++q) {
+          float o = vv[q];
+          if (R1) o += R1[(size_t)grow * ldr1 + gcol + q];
+          if (R2) o += R2[(size_t)grow * ldr2 + gcol + q];
+          if (relu) o = fmaxf(o, 0.f);
+          C[(size_t)grow * ldc + gcol + q] = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
+                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s) {
+  if (M <= 0 || N <= 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kLdsBytes);
+    attr_set = true;
+  }
+  const int tiles_m = (M + kBM - 1) / kBM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;
+  gw = std::max(1, std::min(gw, tiles_n));
+  hipLaunchKernelGGL(gemm_f32_bf16x6_kernel, dim3(n_tiles), dim3(512), kLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2,
+                     ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0);
+}
+
+}  // namespace pfhip

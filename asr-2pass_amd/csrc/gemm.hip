@@ -713,13 +713,16 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
                           hipStream_t s) {
   if (M <= 0 || N <= 0) return;
   const int tiles = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
-  // Large launches go to the BF16 matrix cores (three-way split, six MFMAs per block: gemm_x6.hip) — 1.45-1.5 x the fp32 MFMA
-  // kernel on the encoder shapes, results at least as close to fp64 as the fp32 chain.  PFHIP_GEMM_X6=0 turns it off.
+  // Launches of at least half a round of tiles go to the BF16 matrix cores (exact three-way split, six MFMAs per block:
+  // gemm_x6.hip) — 1.3-1.6 x the fp32 MFMA kernels, results at least as close to fp64 as the fp32 chain.  Its 128 x 128 tile
+  // (two blocks per CU) wins on the K = 512 shapes and on every under-filled grid; the 256 x 128 tile on long-K launches that
+  // fill the chip (FFN2 at full batch: 201 vs 194 TF).  PFHIP_GEMM_X6=0 turns the path off.
   static const bool x6_on = [] { const char* e = getenv("PFHIP_GEMM_X6"); return !(e && e[0] == '0'); }();
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
-  if (kind == 4 || (kind == 0 && x6_on && M >= 2048 && tiles256 >= 128)) {
+  if (kind == 4 || kind == 5 || (kind == 0 && x6_on && tiles >= 128)) {
+    const bool small_tile = kind == 5 || (kind == 0 && !(K >= 1024 && tiles256 >= 180));
     launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                           column_group_width(M, K, (N + kTileN - 1) / kTileN), s);
+                           column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile);
     return;
   }
   const bool skinny = kind == 2 || (kind == 0 && tiles < kStreamingBelowTiles);

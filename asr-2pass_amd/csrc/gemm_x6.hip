@@ -230,16 +230,181 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
   }
 }
 
+// ---- 128 x 128 sibling for grids that would not fill half a round of 256 x 128 tiles (decoder-side GEMMs over a few thousand
+// token rows, batches of 4-8 utterances, rounds of streaming connections): 8 waves as 2 x 4, each 64 x 32 = 2 x 1 MFMA tiles,
+// LDS 2 x 36,864 B so two blocks share a CU; same staging / split / pipelining scheme (per K-step and wave: 12 MFMAs, 44 VALU
+// ops of splitting, 6 LDS writes, 2 global loads, 9 fragment reads).
+constexpr int kSM = 128;
+constexpr int kSPlane = kSM * kRowB;                        // 6,144 B per plane (A and W tiles have 128 rows each)
+constexpr int kSStageB = 6 * kSPlane;                       // 36,864 B
+constexpr int kSLdsBytes = 2 * kSStageB;                    // 73,728 B
+static_assert(kSM * kCs * 4 <= kSLdsBytes, "C tile must fit the operand buffers");
+
+__global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
+    const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
+    int n_tiles, int gw, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  int tm, tn;
+  tile_of_block_x6(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
+  const int m0 = tm * kSM, n0 = tn * kBN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int srow = tid >> 2, sq = tid & 3;
+  const float* Ag = A + (size_t)min(m0 + srow, M - 1) * lda + 4 * sq;
+  const float* Wg = W + (size_t)min(n0 + srow, N - 1) * ldw + 4 * sq;
+  const int a_st = srow * kRowB + 8 * sq;
+  const int w_st = 3 * kSPlane + a_st;
+  const int a_fr = (wr * 64 + r) * kRowB + 16 * h;
+  const int w_fr = 3 * kSPlane + (wc * 32 + r) * kRowB + 16 * h;
+
+  float4 xa, xw, ya, yw;
+#define PFHIP_LOAD_RAW(RA, RW, k0)                            \
+  RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
+  RW = *reinterpret_cast<const float4*>(Wg + (k0));
+  auto split3 = [&](const float4& v, unsigned char* base) {
+    uint2 p;
+    p.x = top16_pair(v.x, v.y); p.y = top16_pair(v.z, v.w);
+    *reinterpret_cast<uint2*>(base) = p;
+    float4 s = make_float4(rest(v.x), rest(v.y), rest(v.z), rest(v.w));
+    p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
+    *reinterpret_cast<uint2*>(base + kSPlane) = p;
+    s = make_float4(rest(s.x), rest(s.y), rest(s.z), rest(s.w));
+    p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
+    *reinterpret_cast<uint2*>(base + 2 * kSPlane) = p;
+  };
+#define PFHIP_SPLIT_STORE(RA, RW, stage)                      \
+  split3(RA, lds + (stage) * kSStageB + a_st);                \
+  split3(RW, lds + (stage) * kSStageB + w_st);
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+
+  bf16x8 fa[3][2], fb[3], ga[3][2], gb[3];
+#define PFHIP_FRAGS(FA, FB, stage)                                                                                  \
+  _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
+    FA[p][0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kSStageB + p * kSPlane + a_fr));               \
+    FA[p][1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kSStageB + p * kSPlane + a_fr + 32 * kRowB));  \
+    FB[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kSStageB + p * kSPlane + w_fr));                  \
+  }
+#define PFHIP_X6(FA, FB, pa, pb)                                                          \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa][0], FB[pb], acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa][1], FB[pb], acc1, 0, 0, 0);
+#define PFHIP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, nxt, knext)                                        \
+  PFHIP_SPLIT_STORE(RA, RW, nxt)                                                              \
+  PFHIP_LOAD_RAW(RA, RW, knext)                                                               \
+  PFHIP_X6(FA, FB, 1, 1) PFHIP_X6(FA, FB, 0, 2) PFHIP_X6(FA, FB, 2, 0) PFHIP_X6(FA, FB, 0, 1)  \
+  _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                             \
+    PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1);                                \
+  }                                                                                           \
+  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 1); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 1);               \
+  __builtin_amdgcn_sched_barrier(0);                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
+  __builtin_amdgcn_sched_barrier(0);                                                          \
+  PFHIP_FRAGS(GA, GB, nxt)                                                                    \
+  PFHIP_X6(FA, FB, 1, 0) PFHIP_X6(FA, FB, 0, 0)                                               \
+  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 3); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 2);             \
+  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 2); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 2);             \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int nk = K / kBK;
+  auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
+  PFHIP_LOAD_RAW(xa, xw, 0)
+  PFHIP_SPLIT_STORE(xa, xw, 0)
+  PFHIP_LOAD_RAW(ya, yw, kclamp(1))
+  PFHIP_LOAD_RAW(xa, xw, kclamp(2))
+  __syncthreads();
+  PFHIP_FRAGS(fa, fb, 0)
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    { const int knext = kclamp(kt + 3); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
+    { const int knext = kclamp(kt + 4); PFHIP_STEP(ga, gb, fa, fb, xa, xw, 0, knext) }
+  }
+  if (kt < nk) { const int knext = kclamp(nk); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
+#undef PFHIP_STEP
+#undef PFHIP_SPLIT_STORE
+#undef PFHIP_LOAD_RAW
+#undef PFHIP_SGB
+#undef PFHIP_X6
+#undef PFHIP_FRAGS
+  __syncthreads();
+
+  float* const Cs = reinterpret_cast<float*>(lds);
+  {
+    float* cw = Cs + (wr * 64 + 4 * h) * kCs + wc * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ro = ((e & 3) + 8 * (e >> 2)) * kCs;
+      cw[ro] = acc0[e];
+      cw[ro + 32 * kCs] = acc1[e];
+    }
+  }
+  __syncthreads();
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    else {
+      if (gcol < N) bv.x = bias[gcol];
+      if (gcol + 1 < N) bv.y = bias[gcol + 1];
+      if (gcol + 2 < N) bv.z = bias[gcol + 2];
+    }
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 16 + rsub;
+    const int grow = m0 + row;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (grow < M && gcol + 3 < N) {
+      if (R1) {
+        const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (R2) {
+        const float4 t = *reinterpret_cast<const float4*>(R2 + (size_t)grow * ldr2 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+    } else if (grow < M && gcol < N) {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int q = 0; q < 4 && gcol + q < N; ++q) {
+        float o = vv[q];
+        if (R1) o += R1[(size_t)grow * ldr1 + gcol + q];
+        if (R2) o += R2[(size_t)grow * ldr2 + gcol + q];
+        if (relu) o = fmaxf(o, 0.f);
+        C[(size_t)grow * ldc + gcol + q] = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
-                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s) {
+                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile) {
   if (M <= 0 || N <= 0) return;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kSLdsBytes);
     attr_set = true;
+  }
+  if (small_tile) {
+    const int tiles_m = (M + kSM - 1) / kSM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;
+    gw = std::max(1, std::min(gw, tiles_n));
+    hipLaunchKernelGGL(gemm_f32_bf16x6_128_kernel, dim3(n_tiles), dim3(512), kSLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2,
+                       ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0);
+    return;
   }
   const int tiles_m = (M + kBM - 1) / kBM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;
   gw = std::max(1, std::min(gw, tiles_n));

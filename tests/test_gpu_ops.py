@@ -33,7 +33,7 @@ def pad_rows(a, m=128):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 32), (128, 128, 32), (130, 512, 512), (500, 1536, 576),
                                    (257, 1003, 512), (16, 512, 2048), (1000, 2048, 512)])
 @pytest.mark.parametrize("guard", [True, False])
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])    # by size / 128x128 tiles / weight-streaming / 64x128 tiles / bf16 split
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5])    # by size / 128x128 / weight-streaming / 64x128 / bf16 split 256x128, 128x128
 def test_gemm_matches_numpy(ops, M, N, K, guard, kind):
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -201,7 +201,7 @@ def test_gemm_random_shapes_all_kernels(ops):
         dbias = dev(np.concatenate([bias, np.zeros(Np - N, np.float32)]))
         dR1 = dev(np.pad(pad_rows(R1), ((0, 0), (0, Np - N))))
         ref = np.maximum(A @ W.T + bias + R1, 0)
-        for kind in (1, 2, 3, 4):
+        for kind in (1, 2, 3, 4, 5):
             C = ops.gemm_f32(dA, dW, bias=dbias, R1=dR1, relu=True, M=M, N=N, guard=True, kind=kind).cpu().numpy()
             assert np.abs(C[:M, :N] - ref).max() < 3e-5 * max(1.0, np.sqrt(K / 512)), (M, N, K, kind)
 
@@ -219,12 +219,13 @@ def test_gemm_bf16_split_is_fp32_grade(ops):
     ref = A.astype(np.float64) @ W.astype(np.float64).T
     norm = np.sqrt((A.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
     err = {}
-    for kind in (1, 4):
+    for kind in (1, 4, 5):
         C = ops.gemm_f32(dA, dW, M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
         err[kind] = float((np.abs(C - ref) / norm).max())
-    assert err[4] <= 1.5 * err[1] + 1e-9, err
-    assert err[4] < 5e-7, err
+    assert err[4] <= 1.5 * err[1] + 1e-9 and err[5] <= 1.5 * err[1] + 1e-9, err
+    assert err[4] < 5e-7 and err[5] < 5e-7, err
     Ai = rng.integers(-700, 700, (300, 32)).astype(np.float32)                 # 10-bit operands (two planes); sums < 2^24: exact
     Wi = rng.integers(-700, 700, (256, 32)).astype(np.float32)
-    C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=4).cpu().numpy()[:300, :256]
-    assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))
+    for kind in (4, 5):
+        C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=kind).cpu().numpy()[:300, :256]
+        assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))

@@ -111,9 +111,6 @@ struct StreamReq;
 struct pfhip_model {
   int device = 0;
   hipStream_t own_stream = nullptr;
-  // side stream: the FSMN memory of an encoder layer (HBM-bound) runs beside the layer's attention (MFMA-bound)
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::mutex mu;
   Config cfg;
   int feat_dim = 560, feat_pad = 576, vocab_pad = 8448;

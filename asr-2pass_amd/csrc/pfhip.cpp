@@ -292,9 +292,6 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     if ((st = upload(&m->d_inv_ts, inv))) return st;
   }
   HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   for (auto& kv : m->t) kv.second.h = nullptr;
   *out = m.release();
   return PFHIP_OK;
@@ -402,8 +399,6 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   double attn_pairs = 0;
   for (int b = 0; b < B; ++b) attn_pairs += (double)m->T[b] * m->T[b];
   float* x = m->x.f();
-  static const bool side_on = [] { const char* e = getenv("PFHIP_SIDE_STREAM"); return !(e && e[0] == '0'); }();
-  const bool side_ok = side_on && M >= 4096;       // small launches are latency-bound: nothing to overlap
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
     const bool first = i == 0;
@@ -412,17 +407,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     lnorm(m, s, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
     gemm(m, s, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
          m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
-    // The FSMN memory (depthwise conv on V, HBM-bound) and the attention (MFMA-bound) both read qkv and meet again in the
-    // out-projection's epilogue: the memory runs on a side stream beside the attention.  With the per-class profiler on,
-    // everything stays on one stream so that the class timings mean what they say.
-    const bool fork = side_ok && !(m->prof_mask & ((1 << K_FSMN) | (1 << K_ATTN)));
-    if (fork) {
-      HIP_TRY(hipEventRecord(m->ev_fork, s));
-      HIP_TRY(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
-      pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, m->m_row_off,
-                         m->m_len, B, m->maxT, d, m->side_stream);
-      HIP_TRY(hipEventRecord(m->ev_join, m->side_stream));
-    } else {
+    {
       Scope sc(m, s, K_FSMN, 2.0 * 11 * M * d, 8.0 * M * d);
       pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, m->m_row_off,
                          m->m_len, B, m->maxT, d, s);
@@ -432,7 +417,6 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
       pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d,
                               m->m_row_off, m->m_len, m->m_row_off, m->m_len, B, c.n_head, m->maxT, att_scale, s);
     }
-    if (fork) HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
     // x = (first ? 0 : x) + ctx*Wo + b + fsmn_memory
     gemm(m, s, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
          first ? nullptr : x, d, M, false);
@@ -766,9 +750,6 @@ void pfhip_destroy(pfhip_model* m) {
   if (m->h_counts) (void)hipHostFree(m->h_counts);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
-  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
-  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   delete m;
 }
 

@@ -62,10 +62,10 @@ def max_over_ranks(dt: float, dist, device):
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01/pmc_hbm_traffic_c.json: FETCH_SIZE x2 +
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01/pmc_hbm_traffic_d.json: FETCH_SIZE x2 +
     WRITE_SIZE, collected with rocprofv3 in separate --pmc runs of this same command); PMC counters cannot be read from
     inside the timed run, so this is the last profiled value, or null when the file is absent."""
-    for name in ("pmc_hbm_traffic_c.json", "pmc_hbm_traffic.json"):
+    for name in ("pmc_hbm_traffic_d.json", "pmc_hbm_traffic_c.json", "pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", "r01", name)) as f:
                 return json.load(f)["gemm_avg_bytes_per_launch"]
@@ -205,7 +205,7 @@ def main():
             out["roofline"] = {
                 # achieved = ALGORITHMIC fp32 flops (2*M*N*K) per second; the dominant kernel executes 6 bf16 MFMAs per block,
                 # so its ceiling is the BF16 dense peak / 6 (executed MFMA rate = 6 x achieved, against 2500)
-                "bound": "mfma", "kernel": "gemm_f32_bf16x6_kernel", "achieved": ach, "peak": X6_PEAK_TFLOPS,
+                "bound": "mfma", "kernel": "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel", "achieved": ach, "peak": X6_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / X6_PEAK_TFLOPS, "traffic": pmc_traffic(),
                 "executed_mfma_tflops": ach * X6_MFMAS_PER_BLOCK, "executed_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": F32_MFMA_PEAK_TFLOPS,

@@ -19,6 +19,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace pfhip {
 namespace {
@@ -391,13 +392,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile) {
   if (M <= 0 || N <= 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // > 64 KB of dynamic LDS needs the opt-in once per device
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_done.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kSLdsBytes);
-    attr_set = true;
+    attr_done.fetch_or(1ull << (dev & 63));
   }
   if (small_tile) {
     const int tiles_m = (M + kSM - 1) / kSM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;

@@ -18,6 +18,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace pfhip {
 namespace {
@@ -293,6 +294,13 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                          int max_q_len, float scale, int head_dim, hipStream_t s) {
   if (B <= 0 || max_q_len <= 0) return;
+  // d_k = 128 without per-query limits (encoder self-attention, decoder cross-attention): both products on the BF16 matrix
+  // cores with the exact three-way split (attention_x6.hip) — 1.5 x this file's fp32-MFMA kernel.  PFHIP_ATT_X6=0 keeps fp32.
+  static const bool x6 = [] { const char* e = getenv("PFHIP_ATT_X6"); return !(e && e[0] == '0'); }();
+  if (x6 && head_dim == 128) {
+    launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s);
+    return;
+  }
   const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(256);
   if (head_dim == 32)
     hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,

@@ -1,0 +1,289 @@
+// Fused attention with both products on the BF16 matrix cores (exact three-way bf16 split of Q, K, V and of the
+// probabilities; six `v_mfma_f32_32x32x16_bf16` per fp32 block, fp32 accumulation — the scheme of gemm_x6.hip), d_k = 128,
+// flash-style online softmax.  Sibling of attention.hip (fp32 MFMA), same interface; the default for d_k = 128 (PFHIP_ATT_X6=0 opts out).
+//
+// One workgroup = 8 waves = 256 query rows of one (utterance, head); a wave keeps its 32 queries' Q planes in registers
+// (pre-multiplied by scale*log2 e, then split).  Per 32-key tile:
+//   S^T = K Q^T   A operand = K planes from LDS ([key][d] rows, ds_read_b128), B operand = Q planes (registers): 8 k-steps x 6;
+//                 a query's 32 scores sit in one lane pair, softmax as in attention.hip;
+//   O^T += V^T P^T  B operand = the probabilities, split in registers — lane half h holds keys (e&3)+8(e>>2)+4h, so k-slot i of
+//                 step t is key 16t + 8(i>>2) + (i&3) + 4h; the A operand takes the SAME keys from the transposed V planes in LDS
+//                 ([d][key] rows: two ds_read_b64), so the permutation cancels: 4 d-tiles x 2 k-steps x 6.
+// K / V tiles are split while they are staged (global fp32 -> registers -> bf16 planes in LDS; V transposed on the way by
+// loading 4 keys x 4 d per thread), double-buffered, one barrier per tile.
+#include "kernels.h"
+
+#include <math.h>
+
+#include <atomic>
+
+namespace pfhip {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int kHD = 128, kQW = 32, kNW = 8, kQB = kNW * kQW, kKT = 32;   // 8 waves = 256 queries per workgroup, two waves per SIMD
+constexpr int kKRow = 272;                       // bytes per key row of a K plane (128 bf16 + 16 pad: conflict-free b128 reads)
+constexpr int kKPlane = kKT * kKRow;             // 8,704
+constexpr int kVRow = 80;                        // bytes per d row of a V^T plane (32 keys bf16 + 16 pad)
+constexpr int kVPlane = kHD * kVRow;             // 10,240
+constexpr int kBuf = 3 * kKPlane + 3 * kVPlane;  // 56,832
+constexpr int kOS = kHD + 4;                     // floats per row of the output transpose tile
+constexpr int kLdsBytes = kNW * kQW * kOS * 4;    // 135,168: the output transpose tile (>= 2 * kBuf = 113,664)
+static_assert(kLdsBytes >= 2 * kBuf, "K/V buffers must fit");
+
+__device__ __forceinline__ unsigned top16_pair(float lo, float hi) {
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+
+// 8 fp32 values -> their three bf16 planes, packed as MFMA operands
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+  float s[8], t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s[i] = rest(v[i]); t[i] = rest(s[i]); }
+  uint4 a, b, c;
+  a.x = top16_pair(v[0], v[1]); a.y = top16_pair(v[2], v[3]); a.z = top16_pair(v[4], v[5]); a.w = top16_pair(v[6], v[7]);
+  b.x = top16_pair(s[0], s[1]); b.y = top16_pair(s[2], s[3]); b.z = top16_pair(s[4], s[5]); b.w = top16_pair(s[6], s[7]);
+  c.x = top16_pair(t[0], t[1]); c.y = top16_pair(t[2], t[3]); c.z = top16_pair(t[4], t[5]); c.w = top16_pair(t[6], t[7]);
+  p0 = __builtin_bit_cast(bf16x8, a); p1 = __builtin_bit_cast(bf16x8, b); p2 = __builtin_bit_cast(bf16x8, c);
+}
+
+__global__ __launch_bounds__(512, 1) void attention_x6_kernel(
+    const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
+    float* __restrict__ O, int ldo, const int* __restrict__ q_off, const int* __restrict__ q_len,
+    const int* __restrict__ kv_off, const int* __restrict__ kv_len, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int b = blockIdx.y, head = blockIdx.x;
+  const int Lq = q_len[b];
+  const int q0 = blockIdx.z * kQB;
+  if (q0 >= Lq) return;
+  const int Lk = kv_len[b];
+  const size_t qbase = (size_t)q_off[b], kbase = (size_t)kv_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- Q planes of this lane: query row q0 + wave*32 + r, k-step s covers d = 16s + 8h + (0..7) ----------------------------
+  bf16x8 qf[8][3];
+  {
+    int qrow = q0 + wave * kQW + r;
+    if (qrow >= Lq) qrow = Lq - 1;
+    const float* qp = Q + (qbase + qrow) * ldq + head * kHD + 8 * h;
+    const float qs = scale * 1.44269504088896340736f;          // scores come out in the base-2 softmax domain
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(qp + 16 * s);
+      const float4 c = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+      const float v[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, c.x * qs, c.y * qs, c.z * qs, c.w * qs};
+      split8(v, qf[s][0], qf[s][1], qf[s][2]);
+    }
+  }
+
+  // ---- staging maps (512 threads) ---------------------------------------------------------------------------------------
+  // K: thread t holds key t/16, d = 64 i + 4 (t%16) + (0..3), i = 0..1 (a load instruction covers 256 contiguous bytes per key)
+  const int kkey = tid >> 4, kc = tid & 15;
+  const float* Kh = K + kbase * ldk + head * kHD + 4 * kc;
+  // V: thread t holds keys 4 (t/64) + (0..3), d = 2 (t%64) + (0..1): its 4 x 2 patch transposes in registers
+  const int vd2 = tid & 63, vkg = tid >> 6;
+  const float* Vh = V + kbase * ldv + head * kHD + 2 * vd2;
+  float4 rk0, rk1;
+  float2 rv0, rv1, rv2, rv3;
+  auto load_tile = [&](int kt) {
+    int key = kt * kKT + kkey;
+    key = key < Lk ? key : Lk - 1;
+    const float* kp = Kh + (size_t)key * ldk;
+    rk0 = *reinterpret_cast<const float4*>(kp);
+    rk1 = *reinterpret_cast<const float4*>(kp + 64);
+    const int k0 = kt * kKT + 4 * vkg;
+    const int last = Lk - 1;
+    rv0 = *reinterpret_cast<const float2*>(Vh + (size_t)min(k0, last) * ldv);
+    rv1 = *reinterpret_cast<const float2*>(Vh + (size_t)min(k0 + 1, last) * ldv);
+    rv2 = *reinterpret_cast<const float2*>(Vh + (size_t)min(k0 + 2, last) * ldv);
+    rv3 = *reinterpret_cast<const float2*>(Vh + (size_t)min(k0 + 3, last) * ldv);
+  };
+  auto store4 = [&](float a, float c, float e, float g, unsigned char* base, int plane_bytes) {   // 4 values -> 3 planes, 8 B each
+    uint2 p;
+    p.x = top16_pair(a, c); p.y = top16_pair(e, g);
+    *reinterpret_cast<uint2*>(base) = p;
+    const float a1 = rest(a), c1 = rest(c), e1 = rest(e), g1 = rest(g);
+    p.x = top16_pair(a1, c1); p.y = top16_pair(e1, g1);
+    *reinterpret_cast<uint2*>(base + plane_bytes) = p;
+    p.x = top16_pair(rest(a1), rest(c1)); p.y = top16_pair(rest(e1), rest(g1));
+    *reinterpret_cast<uint2*>(base + 2 * plane_bytes) = p;
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* kb = lds + buf * kBuf + kkey * kKRow + 8 * kc;                    // d = 4 kc -> byte 8 kc; + 128 B per i
+    store4(rk0.x, rk0.y, rk0.z, rk0.w, kb, kKPlane);
+    store4(rk1.x, rk1.y, rk1.z, rk1.w, kb + 128, kKPlane);
+    unsigned char* vb = lds + buf * kBuf + 3 * kKPlane + (2 * vd2) * kVRow + 8 * vkg;   // row d, keys 4 vkg .. + 3
+    store4(rv0.x, rv1.x, rv2.x, rv3.x, vb, kVPlane);
+    store4(rv0.y, rv1.y, rv2.y, rv3.y, vb + kVRow, kVPlane);
+  };
+
+  f32x16 oacc0, oacc1, oacc2, oacc3;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { oacc0[e] = 0.f; oacc1[e] = 0.f; oacc2[e] = 0.f; oacc3[e] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nkt = (Lk + kKT - 1) / kKT;
+  load_tile(0);
+  store_tile(0);
+  load_tile(nkt > 1 ? 1 : 0);                          // raw registers run one tile ahead of the LDS buffers
+  __syncthreads();
+
+#define PFHIP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const unsigned char* kb = lds + cur * kBuf + r * kKRow + 16 * h;
+    const unsigned char* vb = lds + cur * kBuf + 3 * kKPlane + r * kVRow + 8 * h;
+
+    // S^T[key][q]: 8 k-steps x 6 plane products.  The split of the NEXT tile (176 VALU ops, 24 LDS writes into the other
+    // buffer) and this tile's 24 K-fragment reads are issued between the 48 MFMAs (masks: 0x8 MFMA, 0x2 VALU, 0x200 DS
+    // write, 0x100 DS read, 0x20 VMEM read).
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    store_tile(cur ^ 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + 32 * s));
+      const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + kKPlane + 32 * s));
+      const bf16x8 k2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + 2 * kKPlane + 32 * s));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s][1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s][2], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[s][0], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s][1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s][0], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s][0], sacc, 0, 0, 0);
+    }
+    PFHIP_SGB(0x100, 3);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 4); PFHIP_SGB(0x100, 1);
+      PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 4); PFHIP_SGB(0x200, 1);
+      PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 1);
+      PFHIP_SGB(0x8, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);      // past the end: re-fetch the last tile (never used)
+    __builtin_amdgcn_sched_barrier(0);
+
+    // online softmax (base 2) for query column r; this lane holds keys (e&3) + 8*(e>>2) + 4*h of the tile
+    float tmax = -INFINITY;
+    if ((kt + 1) * kKT <= Lk) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
+    } else {
+      const int key0 = kt * kKT + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2);
+        const float sv = (key < Lk) ? sacc[e] : -INFINITY;
+        sacc[e] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(sacc[e] - m_new);
+      sacc[e] = pv;
+      psum += pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { oacc0[e] *= alpha; oacc1[e] *= alpha; oacc2[e] *= alpha; oacc3[e] *= alpha; }
+    }
+
+    // O^T[d][q] += V^T P^T: two k-steps of 16 keys; k-slot i of step t is register e = 8t + i of the score tile
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float pv[8] = {sacc[8 * t + 0], sacc[8 * t + 1], sacc[8 * t + 2], sacc[8 * t + 3],
+                           sacc[8 * t + 4], sacc[8 * t + 5], sacc[8 * t + 6], sacc[8 * t + 7]};
+      bf16x8 p0, p1, p2;
+      split8(pv, p0, p1, p2);
+#define PFHIP_PV(OACC, dt)                                                                                        \
+      {                                                                                                           \
+        const unsigned char* vp = vb + (dt) * 32 * kVRow + 32 * t;                                                \
+        bf16x8 v0, v1, v2;                                                                                        \
+        {                                                                                                         \
+          const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 16);    \
+          v0 = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                                    \
+        }                                                                                                         \
+        {                                                                                                         \
+          const uint2 lo = *reinterpret_cast<const uint2*>(vp + kVPlane), hi = *reinterpret_cast<const uint2*>(vp + kVPlane + 16); \
+          v1 = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                                    \
+        }                                                                                                         \
+        {                                                                                                         \
+          const uint2 lo = *reinterpret_cast<const uint2*>(vp + 2 * kVPlane), hi = *reinterpret_cast<const uint2*>(vp + 2 * kVPlane + 16); \
+          v2 = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                                    \
+        }                                                                                                         \
+        OACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, OACC, 0, 0, 0);                                    \
+        OACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p2, OACC, 0, 0, 0);                                    \
+        OACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, p0, OACC, 0, 0, 0);                                    \
+        OACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p1, OACC, 0, 0, 0);                                    \
+        OACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p0, OACC, 0, 0, 0);                                    \
+        OACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p0, OACC, 0, 0, 0);                                    \
+      }
+      PFHIP_PV(oacc0, 0) PFHIP_PV(oacc1, 1) PFHIP_PV(oacc2, 2) PFHIP_PV(oacc3, 3)
+#undef PFHIP_PV
+    }
+    __syncthreads();
+  }
+#undef PFHIP_SGB
+
+  // ---- normalise, transpose through LDS, store full rows (as attention.hip) ---------------------------------------------
+  const float inv_l = 1.0f / l_run;
+  float* os = reinterpret_cast<float*>(lds) + wave * (kQW * kOS);
+#define PFHIP_O_STORE(OACC, dt)                                                          \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
+    float4 o4;                                                                           \
+    o4.x = OACC[4 * g + 0] * inv_l; o4.y = OACC[4 * g + 1] * inv_l;                      \
+    o4.z = OACC[4 * g + 2] * inv_l; o4.w = OACC[4 * g + 3] * inv_l;                      \
+    *reinterpret_cast<float4*>(os + r * kOS + (dt) * 32 + 8 * g + 4 * h) = o4;           \
+  }
+  PFHIP_O_STORE(oacc0, 0) PFHIP_O_STORE(oacc1, 1) PFHIP_O_STORE(oacc2, 2) PFHIP_O_STORE(oacc3, 3)
+#undef PFHIP_O_STORE
+  __syncthreads();
+  {
+    constexpr int C4 = kHD / 4, RW = 64 / C4;
+#pragma unroll
+    for (int pass = 0; pass < kQW / RW; ++pass) {
+      const int row = pass * RW + lane / C4, cc = lane % C4;
+      const int qrow = q0 + wave * kQW + row;
+      if (qrow < Lq) {
+        const float4 o4 = *reinterpret_cast<const float4*>(os + row * kOS + 4 * cc);
+        *reinterpret_cast<float4*>(O + (qbase + qrow) * ldo + head * kHD + 4 * cc) = o4;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
+                         float scale, hipStream_t s) {
+  if (B <= 0 || max_q_len <= 0) return;
+  static std::atomic<unsigned long long> attr_done{0};      // > 64 KB of dynamic LDS needs the opt-in once per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_done.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kLdsBytes);
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(512);
+  hipLaunchKernelGGL(attention_x6_kernel, grid, block, kLdsBytes, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
+                     kv_len, scale);
+}
+
+}  // namespace pfhip

@@ -84,6 +84,10 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
 
 // With a per-query key limit: query row i (packed index) only sees keys [0, min(kv_len, q_kv_limit[i])) — the
 // prefix mask CTTransformerOnline::VadMask builds (ct-transformer-online.cpp:225-240).
+// both attention products on the BF16 matrix cores (exact three-way split, attention_x6.hip); d_k = 128, no per-query limits
+void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
+                         float scale, hipStream_t s);
 void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                              const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
                              const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s);

@@ -229,3 +229,18 @@ def test_gemm_bf16_split_is_fp32_grade(ops):
     for kind in (4, 5):
         C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=kind).cpu().numpy()[:300, :256]
         assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))
+
+
+def test_fp32_mfma_kernels_behind_the_opt_out_knobs():
+    """PFHIP_ATT_X6=0 / PFHIP_GEMM_X6=0 keep everything on the fp32-MFMA kernels (the knobs are read once per process, hence
+    a child process): the d_k = 128 attention cases above and the full-size oracle comparison must pass there too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PFHIP_ATT_X6="0", PFHIP_GEMM_X6="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_ops.py", "tests/test_gpu_forward.py",
+                          "-k", "attention_self or attention_cross or attention_rescale or full_size_batch_matches_oracle"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

@@ -26,11 +26,11 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kHD = 128, kQW = 32, kNW = 8, kQB = kNW * kQW, kKT = 32;   // 8 waves = 256 queries per workgroup, two waves per SIMD
 constexpr int kKRow = 272;                       // bytes per key row of a K plane (128 bf16 + 16 pad: conflict-free b128 reads)
 constexpr int kKPlane = kKT * kKRow;             // 8,704
-constexpr int kVRow = 80;                        // bytes per d row of a V^T plane (32 keys bf16 + 16 pad)
-constexpr int kVPlane = kHD * kVRow;             // 10,240
-constexpr int kBuf = 3 * kKPlane + 3 * kVPlane;  // 56,832
+constexpr int kVRow = 72;                        // bytes per d row of a V^T plane (32 keys bf16 + 8 pad: conflict-free b64 reads)
+constexpr int kVPlane = kHD * kVRow;             // 9,216
+constexpr int kBuf = 3 * kKPlane + 3 * kVPlane;  // 53,760
 constexpr int kOS = kHD + 4;                     // floats per row of the output transpose tile
-constexpr int kLdsBytes = kNW * kQW * kOS * 4;    // 135,168: the output transpose tile (>= 2 * kBuf = 113,664)
+constexpr int kLdsBytes = kNW * kQW * kOS * 4;    // 135,168: the output transpose tile (>= 2 * kBuf = 107,520)
 static_assert(kLdsBytes >= 2 * kBuf, "K/V buffers must fit");
 
 __device__ __forceinline__ unsigned top16_pair(float lo, float hi) {
@@ -186,22 +186,26 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
       }
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // Lazy rescale: the running reference m_run only moves when some query's maximum has outgrown it by more than 2^16 —
+    // the probabilities are then at most 2^16 (exact in the bf16 planes like any fp32 value) and the 64 accumulator
+    // multiplies per tile disappear from all but the first tiles; p / l is the same quotient either way.
+    if (__any(tmax > m_run + 16.0f)) {
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { oacc0[e] *= alpha; oacc1[e] *= alpha; oacc2[e] *= alpha; oacc3[e] *= alpha; }
+    }
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(sacc[e] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(sacc[e] - m_run);
       sacc[e] = pv;
       psum += pv;
     }
     psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (__any(alpha != 1.0f)) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { oacc0[e] *= alpha; oacc1[e] *= alpha; oacc2[e] *= alpha; oacc3[e] *= alpha; }
-    }
+    l_run += psum;
 
     // O^T[d][q] += V^T P^T: two k-steps of 16 keys; k-slot i of step t is register e = 8t + i of the score tile
 #pragma unroll

@@ -139,33 +139,92 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
     const unsigned char* kb = lds + cur * kBuf + r * kKRow + 16 * h;
     const unsigned char* vb = lds + cur * kBuf + 3 * kKPlane + r * kVRow + 8 * h;
 
-    // S^T[key][q]: 8 k-steps x 6 plane products.  The split of the NEXT tile (176 VALU ops, 24 LDS writes into the other
-    // buffer) and this tile's 24 K-fragment reads are issued between the 48 MFMAs (masks: 0x8 MFMA, 0x2 VALU, 0x200 DS
-    // write, 0x100 DS read, 0x20 VMEM read).
+    // S^T[key][q]: 8 k-steps x 6 plane products.  The split of the NEXT tile (its 12 stages of ~8 VALU ops + one LDS write
+    // into the other buffer) and the K-fragment reads of the next k-step are placed by hand between the MFMAs and pinned with
+    // scheduling barriers: left to the compiler (sched_group_barrier patterns included) all of the split ran before the
+    // first MFMA.
     f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    store_tile(cur ^ 1);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + 32 * s));
-      const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + kKPlane + 32 * s));
-      const bf16x8 k2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + 2 * kKPlane + 32 * s));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s][1], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s][2], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[s][0], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s][1], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s][0], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s][0], sacc, 0, 0, 0);
-    }
-    PFHIP_SGB(0x100, 3);
-#pragma unroll
-    for (int q = 0; q < 12; ++q) {
-      PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 4); PFHIP_SGB(0x100, 1);
-      PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 4); PFHIP_SGB(0x200, 1);
-      PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 1);
-      PFHIP_SGB(0x8, 1);
-    }
+    unsigned char* const kst = lds + (cur ^ 1) * kBuf + kkey * kKRow + 8 * kc;
+    unsigned char* const vst = lds + (cur ^ 1) * kBuf + 3 * kKPlane + (2 * vd2) * kVRow + 8 * vkg;
+    float t0, t1, t2, t3;
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_KF(dst, p, s_) dst = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kb + (p) * kKPlane + 32 * (s_)))
+#define PFHIP_MM(a_, b_) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, sacc, 0, 0, 0)
+    bf16x8 k0, k1, k2, n0, n1, n2;
+    PFHIP_KF(k0, 0, 0); PFHIP_KF(k1, 1, 0); PFHIP_KF(k2, 2, 0);
+    PFHIP_SB;
+    PFHIP_MM(k1, qf[0][1]); PFHIP_SB;
+    PFHIP_KF(n0, 0, 1); PFHIP_KF(n1, 1, 1); PFHIP_KF(n2, 2, 1); PFHIP_SB;
+    PFHIP_MM(k0, qf[0][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(rk0.x, rk0.y); p_.y = top16_pair(rk0.z, rk0.w); *reinterpret_cast<uint2*>(kst) = p_; t0 = rest(rk0.x); t1 = rest(rk0.y); t2 = rest(rk0.z); t3 = rest(rk0.w); } PFHIP_SB;
+    PFHIP_MM(k2, qf[0][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[0][1]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(kst + kKPlane) = p_; t0 = rest(t0); t1 = rest(t1); t2 = rest(t2); t3 = rest(t3); } PFHIP_SB;
+    PFHIP_MM(k1, qf[0][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[0][0]); PFHIP_SB;
+    PFHIP_MM(n1, qf[1][1]); PFHIP_SB;
+    PFHIP_KF(k0, 0, 2); PFHIP_KF(k1, 1, 2); PFHIP_KF(k2, 2, 2); PFHIP_SB;
+    PFHIP_MM(n0, qf[1][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(kst + 2 * kKPlane) = p_; } PFHIP_SB;
+    PFHIP_MM(n2, qf[1][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[1][1]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(rk1.x, rk1.y); p_.y = top16_pair(rk1.z, rk1.w); *reinterpret_cast<uint2*>(kst + 128) = p_; t0 = rest(rk1.x); t1 = rest(rk1.y); t2 = rest(rk1.z); t3 = rest(rk1.w); } PFHIP_SB;
+    PFHIP_MM(n1, qf[1][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[1][0]); PFHIP_SB;
+    PFHIP_MM(k1, qf[2][1]); PFHIP_SB;
+    PFHIP_KF(n0, 0, 3); PFHIP_KF(n1, 1, 3); PFHIP_KF(n2, 2, 3); PFHIP_SB;
+    PFHIP_MM(k0, qf[2][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(kst + 128 + kKPlane) = p_; t0 = rest(t0); t1 = rest(t1); t2 = rest(t2); t3 = rest(t3); } PFHIP_SB;
+    PFHIP_MM(k2, qf[2][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[2][1]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(kst + 128 + 2 * kKPlane) = p_; } PFHIP_SB;
+    PFHIP_MM(k1, qf[2][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[2][0]); PFHIP_SB;
+    PFHIP_MM(n1, qf[3][1]); PFHIP_SB;
+    PFHIP_KF(k0, 0, 4); PFHIP_KF(k1, 1, 4); PFHIP_KF(k2, 2, 4); PFHIP_SB;
+    PFHIP_MM(n0, qf[3][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(rv0.x, rv1.x); p_.y = top16_pair(rv2.x, rv3.x); *reinterpret_cast<uint2*>(vst) = p_; t0 = rest(rv0.x); t1 = rest(rv1.x); t2 = rest(rv2.x); t3 = rest(rv3.x); } PFHIP_SB;
+    PFHIP_MM(n2, qf[3][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[3][1]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(vst + kVPlane) = p_; t0 = rest(t0); t1 = rest(t1); t2 = rest(t2); t3 = rest(t3); } PFHIP_SB;
+    PFHIP_MM(n1, qf[3][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[3][0]); PFHIP_SB;
+    PFHIP_MM(k1, qf[4][1]); PFHIP_SB;
+    PFHIP_KF(n0, 0, 5); PFHIP_KF(n1, 1, 5); PFHIP_KF(n2, 2, 5); PFHIP_SB;
+    PFHIP_MM(k0, qf[4][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(vst + 2 * kVPlane) = p_; } PFHIP_SB;
+    PFHIP_MM(k2, qf[4][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[4][1]); PFHIP_SB;
+    PFHIP_MM(k1, qf[4][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[4][0]); PFHIP_SB;
+    PFHIP_MM(n1, qf[5][1]); PFHIP_SB;
+    PFHIP_KF(k0, 0, 6); PFHIP_KF(k1, 1, 6); PFHIP_KF(k2, 2, 6); PFHIP_SB;
+    PFHIP_MM(n0, qf[5][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(rv0.y, rv1.y); p_.y = top16_pair(rv2.y, rv3.y); *reinterpret_cast<uint2*>(vst + kVRow) = p_; t0 = rest(rv0.y); t1 = rest(rv1.y); t2 = rest(rv2.y); t3 = rest(rv3.y); } PFHIP_SB;
+    PFHIP_MM(n2, qf[5][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[5][1]); PFHIP_SB;
+    PFHIP_MM(n1, qf[5][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[5][0]); PFHIP_SB;
+    PFHIP_MM(k1, qf[6][1]); PFHIP_SB;
+    PFHIP_KF(n0, 0, 7); PFHIP_KF(n1, 1, 7); PFHIP_KF(n2, 2, 7); PFHIP_SB;
+    PFHIP_MM(k0, qf[6][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(vst + kVRow + kVPlane) = p_; t0 = rest(t0); t1 = rest(t1); t2 = rest(t2); t3 = rest(t3); } PFHIP_SB;
+    PFHIP_MM(k2, qf[6][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[6][1]); PFHIP_SB;
+    PFHIP_MM(k1, qf[6][0]); PFHIP_SB;
+    PFHIP_MM(k0, qf[6][0]); PFHIP_SB;
+    PFHIP_MM(n1, qf[7][1]); PFHIP_SB;
+    PFHIP_MM(n0, qf[7][2]); PFHIP_SB;
+    { uint2 p_; p_.x = top16_pair(t0, t1); p_.y = top16_pair(t2, t3); *reinterpret_cast<uint2*>(vst + kVRow + 2 * kVPlane) = p_; } PFHIP_SB;
+    PFHIP_MM(n2, qf[7][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[7][1]); PFHIP_SB;
+    PFHIP_MM(n1, qf[7][0]); PFHIP_SB;
+    PFHIP_MM(n0, qf[7][0]); PFHIP_SB;
+#undef PFHIP_MM
+#undef PFHIP_KF
+#undef PFHIP_SB
     __builtin_amdgcn_sched_barrier(0);
     load_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);      // past the end: re-fetch the last tile (never used)
     __builtin_amdgcn_sched_barrier(0);

@@ -62,10 +62,10 @@ def max_over_ranks(dt: float, dist, device):
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01/pmc_hbm_traffic_d.json: FETCH_SIZE x2 +
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01/pmc_hbm_traffic_e.json: FETCH_SIZE x2 +
     WRITE_SIZE, collected with rocprofv3 in separate --pmc runs of this same command); PMC counters cannot be read from
     inside the timed run, so this is the last profiled value, or null when the file is absent."""
-    for name in ("pmc_hbm_traffic_d.json", "pmc_hbm_traffic_c.json", "pmc_hbm_traffic.json"):
+    for name in ("pmc_hbm_traffic_e.json", "pmc_hbm_traffic_d.json", "pmc_hbm_traffic_c.json", "pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", "r01", name)) as f:
                 return json.load(f)["gemm_avg_bytes_per_launch"]

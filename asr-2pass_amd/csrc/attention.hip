@@ -297,7 +297,7 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
   // d_k = 128 without per-query limits (encoder self-attention, decoder cross-attention): both products on the BF16 matrix
   // cores with the exact three-way split (attention_x6.hip) — 1.5 x this file's fp32-MFMA kernel.  PFHIP_ATT_X6=0 keeps fp32.
   static const bool x6 = [] { const char* e = getenv("PFHIP_ATT_X6"); return !(e && e[0] == '0'); }();
-  if (x6 && head_dim == 128) {
+  if (x6 && head_dim == 128 && max_q_len > 64) {      // streaming windows (20 queries) would leave 7 of its 8 waves idle
     launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s);
     return;
   }

@@ -133,7 +133,6 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
   load_tile(nkt > 1 ? 1 : 0);                          // raw registers run one tile ahead of the LDS buffers
   __syncthreads();
 
-#define PFHIP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const unsigned char* kb = lds + cur * kBuf + r * kKRow + 16 * h;
@@ -301,7 +300,6 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
     }
     __syncthreads();
   }
-#undef PFHIP_SGB
 
   // ---- normalise, transpose through LDS, store full rows (as attention.hip) ---------------------------------------------
   const float inv_l = 1.0f / l_run;

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
     "pfhip_set_batching", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
-    "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_profile_enable", "pfhip_profile_read",
+    "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_debug_poke", "pfhip_profile_enable", "pfhip_profile_read",
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch", "pfhip_set_stream_batching",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
@@ -133,6 +133,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_punc_add_punc.argtypes = [vp, vp, ci, vp, ci, ctypes.POINTER(ci)]
     lib.pfhip_punc_infer_batch.argtypes = [vp, vp, vp, vp, ci, vp]
     lib.pfhip_set_punc_batching.argtypes = [vp, ci, ci]
+    lib.pfhip_debug_poke.argtypes = [vp, ctypes.c_char_p, ci]
     lib.pfhip_profile_enable.argtypes = [vp, ci]
     lib.pfhip_profile_read.argtypes = [vp, ctypes.POINTER(_Profile), ci]
     _lib = lib
@@ -402,18 +403,20 @@ class ParaformerOnlineHip:
     def set_debug(self, on=True):
         _check(self._lib, self._lib.pfhip_stream_set_debug(self._h, 1 if on else 0))
 
-    def Forward(self, din, len_=None, input_finished=False):
+    def Forward(self, din, len_=None, input_finished=False, cap=256):
         x = np.ascontiguousarray(din if len_ is None else np.asarray(din)[:len_], dtype=np.float32)
-        ids = np.zeros(256, np.int32)
+        ids = np.zeros(max(cap, 1), np.int32)
         n = ctypes.c_int(0)
         _check(self._lib, self._lib.pfhip_stream_forward(self._h, x.ctypes.data if x.size else None, int(x.size),
-                                                         1 if input_finished else 0, ids.ctypes.data, 256, ctypes.byref(n)))
+                                                         1 if input_finished else 0, ids.ctypes.data, int(cap), ctypes.byref(n)))
         return [int(v) for v in ids[:n.value]]
 
     @staticmethod
-    def forward_batch(streams, dins, input_finished):
+    def forward_batch(streams, dins, input_finished, caps=None):
         """ParaformerOnline::Forward for many connections of one model in one call (pfhip_stream_forward_batch): the chunk
-        windows that are ready are packed into one forward.  Returns one id list per stream."""
+        windows that are ready are packed into one forward.  Returns one id list per stream.  With `caps` (token-buffer
+        capacities per stream) returns (status, id lists, n_tokens) instead of raising: a stream whose buffer is too small
+        gets no ids and n_tokens = the count it needed, the others are served."""
         B = len(streams)
         if B == 0:
             return []
@@ -425,9 +428,12 @@ class ParaformerOnlineHip:
         fin = (ctypes.c_int * B)(*[1 if f else 0 for f in input_finished])
         ids = np.zeros((B, 256), np.int32)
         idp = (ctypes.c_void_p * B)(*[ids[i].ctypes.data for i in range(B)])
-        caps = (ctypes.c_int * B)(*([256] * B))
+        ccaps = (ctypes.c_int * B)(*([256] * B if caps is None else [int(c) for c in caps]))
         nt = (ctypes.c_int * B)()
-        _check(lib, lib.pfhip_stream_forward_batch(hs, B, ptrs, lens, fin, idp, caps, nt))
+        st = lib.pfhip_stream_forward_batch(hs, B, ptrs, lens, fin, idp, ccaps, nt)
+        if caps is not None:
+            return st, [[int(v) for v in ids[i, :min(nt[i], ccaps[i])]] for i in range(B)], [int(v) for v in nt]
+        _check(lib, st)
         return [[int(v) for v in ids[i, :nt[i]]] for i in range(B)]
 
     def get_tensor(self, name: str, cap_floats: int) -> np.ndarray:

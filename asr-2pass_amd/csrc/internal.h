@@ -129,12 +129,13 @@ struct pfhip_model {
 
   // workspace
   Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
-  Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw;
+  Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw, hwkv;
   Buf sseg;                     // StreamSeg descriptors of a streaming batch
   Buf fbk, d_ops;               // streaming batch: fbank frames of all connections, operation descriptors
   void* h_ops = nullptr; size_t h_ops_cap = 0;       // pinned staging of the same (+ the batch's PCM)
   Buf ts_up, ts_gx, ts_y, ts_hx, ts_a2, ts_alphas, ts_peaks, ts_meta;
   bool have_ts = false;
+  int debug_blstm_flag = 0;        // pfhip_debug_poke
   float out2_b = 0.f;
   int n_hw = 0;                  // hotword embeddings resident in `hw` ([n_hw, d])
   void* h_meta = nullptr; size_t h_meta_cap = 0;     // pinned

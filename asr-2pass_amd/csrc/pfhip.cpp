@@ -540,11 +540,12 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, cat, 2 * d, m->W(p + "out.b").d, nullptr, 0, nullptr, 0, ML, false);
     lnorm(m, s, xd, d, m->yd.f(), d, "bias.dec.norm3", ML, d, d);
     gemm(m, s, m->yd.f(), d, m->W("bias.dec.q.w").d, d, d, d, m->qd.f(), d, m->W("bias.dec.q.b").d, nullptr, 0, nullptr, 0, ML, false);
-    gemm(m, s, m->hw.f(), d, m->W("bias.dec.kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W("bias.dec.kv.b").d, nullptr, 0, nullptr, 0,
-         m->n_hw, false);
+    // the hotword K/V projection lives in its own buffer, sized by the hotword count and filled once per hotword set
+    // (set_hotwords_locked) — the audio-side kv workspace only holds Mp rows
+    const float* hwkv = m->hwkv.f();
     {
       Scope sc(m, s, K_ATTN, 4.0 * ML * (double)m->n_hw * d, 8.0 * ML * d);
-      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
+      pfhip::launch_attention(m->qd.f(), d, hwkv, 2 * d, hwkv + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
                               m->m_hw_off, m->m_hw_len, B, c.n_head, m->maxL, att_scale, s);
     }
     gemm(m, s, m->ctxd.f(), d, m->W("bias.dec.out.w").d, d, d, d, cat + d, 2 * d, m->W("bias.dec.out.b").d, nullptr, 0, nullptr,
@@ -573,6 +574,14 @@ pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
   if (m->ts_hx.cap < (size_t)pfhip::kBlstmScratchFloats * 4) {
     HIP_TRY(m->ts_hx.ensure((size_t)pfhip::kBlstmScratchFloats * 4));
     HIP_TRY(hipMemsetAsync(m->ts_hx.p, 0, (size_t)pfhip::kBlstmScratchFloats * 4, s));
+  }
+  // the kernel's error flag is per call: a barrier time-out of an earlier request must not fail this one
+  HIP_TRY(hipMemsetAsync(m->ts_hx.f() + pfhip::kBlstmFlagWord, 0, 4, s));
+  if (m->debug_blstm_flag) {          // test hook (pfhip_debug_poke): this request sees the flag raised, as after a barrier time-out
+    const unsigned one = 1u;
+    HIP_TRY(hipMemcpyAsync(m->ts_hx.f() + pfhip::kBlstmFlagWord, &one, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m->debug_blstm_flag = 0;
   }
   HIP_TRY(m->ts_a2.ensure((size_t)R * 4));
   HIP_TRY(m->ts_alphas.ensure((size_t)R * 4));
@@ -683,8 +692,14 @@ pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
 
 pfhip_status set_hotwords_locked(pfhip_model* m, const float* hw_emb, int H, hipStream_t s) {
   const int d = m->cfg.d_model;
+  if (!m->cfg.contextual) return fail(PFHIP_ERR_UNSUPPORTED, "model has no bias decoder (use_hotword == false)");
   HIP_TRY(m->hw.ensure((size_t)round_up(H, pfhip::kTileM) * d * 4));
   HIP_TRY(hipMemcpyAsync(m->hw.p, hw_emb, (size_t)H * d * 4, hipMemcpyHostToDevice, s));
+  // K/V projection of the bias decoder's cross-attention: constant per hotword set, [round_up(H,128), 2d]
+  HIP_TRY(m->hwkv.ensure((size_t)round_up(H, pfhip::kTileM) * 2 * d * 4));
+  gemm(m, s, m->hw.f(), d, m->W("bias.dec.kv.w").d, 2 * d, d, d, m->hwkv.f(), 2 * d, m->W("bias.dec.kv.b").d, nullptr, 0, nullptr, 0,
+       H, false);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   m->n_hw = H;
   return PFHIP_OK;
@@ -738,7 +753,7 @@ void pfhip_destroy(pfhip_model* m) {
   (void)hipDeviceSynchronize();
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
-                 &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
+                 &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
                  &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
@@ -993,6 +1008,16 @@ pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size
   HIP_TRY(hipStreamSynchronize(s));
   if (n_out) *n_out = n;
   return PFHIP_OK;
+}
+
+// Test hook.  "blstm_flag" != 0: the next timestamp request finds the BLSTM error word raised (as after a step-barrier
+// time-out) and fails; the request after it must succeed again.
+pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
+  g_err.clear();
+  if (!m || !what) return fail(PFHIP_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (std::string(what) == "blstm_flag") { m->debug_blstm_flag = value; return PFHIP_OK; }
+  return fail(PFHIP_ERR_ARG, std::string("unknown debug key ") + what);
 }
 
 pfhip_status pfhip_profile_enable(pfhip_model* m, int on) {

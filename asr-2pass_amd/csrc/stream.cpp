@@ -613,24 +613,28 @@ pfhip_status forward_calls(pfhip_model* m, std::vector<Call>& calls, hipStream_t
   return rc;
 }
 
-}  // namespace
-
-extern "C" {
-
-pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm, const int* n_samples,
-                                        const int* input_finished, int32_t* const* token_ids, const int* cap, int* n_tokens) {
-  last_error().clear();
+// The batched call with one status PER connection: a connection whose token buffer is too small gets PFHIP_ERR_CAPACITY
+// (n_tokens = the count it needed) and the others still receive their ids; only a failure of the shared forward itself
+// fails everybody, and then every stream of the batch is re-initialised (Reset + InitCache) so that its caches do not
+// keep a half-advanced chunk.  Returns the first non-OK status.
+pfhip_status forward_batch_each(pfhip_stream* const* streams, int n_streams, const float* const* pcm, const int* n_samples,
+                                const int* input_finished, int32_t* const* token_ids, const int* cap, int* n_tokens,
+                                pfhip_status* each, std::string* each_err) {
+  auto all = [&](pfhip_status st) {
+    if (each) for (int i = 0; i < n_streams; ++i) { each[i] = st; if (each_err) each_err[i] = last_error(); }
+    return st;
+  };
   if (!streams || n_streams <= 0 || !pcm || !n_samples || !input_finished || !token_ids || !cap || !n_tokens)
     return fail(PFHIP_ERR_ARG, "bad argument");
   pfhip_model* m = streams[0] ? streams[0]->m : nullptr;
-  if (!m) return fail(PFHIP_ERR_ARG, "null stream");
+  if (!m) return all(fail(PFHIP_ERR_ARG, "null stream"));
   std::vector<Call> calls(n_streams);
   for (int i = 0; i < n_streams; ++i) {
     pfhip_stream* s = streams[i];
-    if (!s || s->m != m) return fail(PFHIP_ERR_ARG, "streams of one batch must belong to one model");
-    for (int j = 0; j < i; ++j) if (streams[j] == s) return fail(PFHIP_ERR_ARG, "a stream appears twice in one batch");
-    if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
-    if (n_samples[i] > kMaxSamples) return fail(PFHIP_ERR_ARG, "more than 32000 samples in one streaming call");
+    if (!s || s->m != m) return all(fail(PFHIP_ERR_ARG, "streams of one batch must belong to one model"));
+    for (int j = 0; j < i; ++j) if (streams[j] == s) return all(fail(PFHIP_ERR_ARG, "a stream appears twice in one batch"));
+    if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return all(fail(PFHIP_ERR_ARG, "bad pcm buffer"));
+    if (n_samples[i] > kMaxSamples) return all(fail(PFHIP_ERR_ARG, "more than 32000 samples in one streaming call"));
     calls[i].s = s; calls[i].pcm = pcm[i]; calls[i].n_samples = n_samples[i]; calls[i].fin = input_finished[i] != 0;
     n_tokens[i] = 0;
   }
@@ -639,13 +643,37 @@ pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_stre
   hipStream_t st = m->own_stream;
   m->prof_stream = st;
   pfhip_status rc = forward_calls(m, calls, st);
-  if (rc) return rc;
-  for (int i = 0; i < n_streams; ++i) {
-    if ((int)calls[i].out.size() > cap[i]) return fail(PFHIP_ERR_CAPACITY, "token_ids too small");
-    for (size_t k = 0; k < calls[i].out.size(); ++k) token_ids[i][k] = calls[i].out[k];
-    n_tokens[i] = (int)calls[i].out.size();
+  if (rc) {
+    const std::string why = last_error();
+    for (Call& c : calls) { reset_cache(c.s); (void)init_cache(c.s, st); }
+    (void)hipStreamSynchronize(st);
+    last_error() = why + " (every stream of the batch was reset)";
+    return all(rc);
   }
-  return PFHIP_OK;
+  pfhip_status first = PFHIP_OK;
+  std::string first_err;
+  for (int i = 0; i < n_streams; ++i) {
+    n_tokens[i] = (int)calls[i].out.size();
+    pfhip_status si = PFHIP_OK;
+    if ((int)calls[i].out.size() > cap[i]) {
+      si = fail(PFHIP_ERR_CAPACITY, "token_ids too small (n_tokens holds the count needed; the chunk's ids are lost)");
+      if (!first) { first = si; first_err = last_error(); }
+    } else {
+      for (size_t k = 0; k < calls[i].out.size(); ++k) token_ids[i][k] = calls[i].out[k];
+    }
+    if (each) { each[i] = si; if (each_err) each_err[i] = si ? last_error() : std::string(); }
+  }
+  if (first) last_error() = first_err;
+  return first;
+}
+}  // namespace
+
+extern "C" {
+
+pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm, const int* n_samples,
+                                        const int* input_finished, int32_t* const* token_ids, const int* cap, int* n_tokens) {
+  last_error().clear();
+  return forward_batch_each(streams, n_streams, pcm, n_samples, input_finished, token_ids, cap, n_tokens, nullptr, nullptr);
 }
 
 }  // extern "C"
@@ -669,9 +697,17 @@ void run_requests(const std::vector<StreamReq*>& reqs) {
   std::vector<int> ns(n), fin(n), cap(n), nt(n);
   std::vector<int32_t*> ids(n);
   for (int i = 0; i < n; ++i) { ss[i] = reqs[i]->s; pcm[i] = reqs[i]->pcm; ns[i] = reqs[i]->n; fin[i] = reqs[i]->fin; ids[i] = reqs[i]->ids; cap[i] = reqs[i]->cap; }
-  const pfhip_status st = pfhip_stream_forward_batch(ss.data(), n, pcm.data(), ns.data(), fin.data(), ids.data(), cap.data(), nt.data());
-  const std::string err = pfhip_detail::last_error();
-  for (int i = 0; i < n; ++i) { *reqs[i]->n_out = nt[i]; reqs[i]->st = st; reqs[i]->err = err; }
+  std::vector<pfhip_status> each(n, PFHIP_OK);
+  std::vector<std::string> err(n);
+  pfhip_detail::last_error().clear();
+  const pfhip_status st = forward_batch_each(ss.data(), n, pcm.data(), ns.data(), fin.data(), ids.data(), cap.data(), nt.data(),
+                                             each.data(), err.data());
+  if (st && !each.empty() && each[0] == PFHIP_OK && err[0].empty()) {      // argument-level failure before `each` was filled
+    bool any = false;
+    for (int i = 0; i < n; ++i) any = any || each[i] != PFHIP_OK;
+    if (!any) for (int i = 0; i < n; ++i) { each[i] = st; err[i] = pfhip_detail::last_error(); }
+  }
+  for (int i = 0; i < n; ++i) { *reqs[i]->n_out = nt[i]; reqs[i]->st = each[i]; reqs[i]->err = err[i]; }
 }
 
 pfhip_status stream_forward_queued(pfhip_model* m, StreamReq& me) {

@@ -148,7 +148,12 @@ pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_sampl
 /* The same call for n_streams connections of ONE model at once (each stream at most once): every connection runs its own
  * ParaformerOnline::Forward control flow, and the encoder windows that are ready are packed into one forward (a 20-row
  * window costs the full weight stream and ~700 launches whatever its size).  Results are identical to n_streams separate
- * pfhip_stream_forward calls.  token_ids[i] has room for cap[i] ids; n_tokens[i] receives the count. */
+ * pfhip_stream_forward calls.  token_ids[i] has room for cap[i] ids; n_tokens[i] receives the count.
+ * Errors are per connection where they can be: a connection whose cap[i] is too small receives no ids and n_tokens[i] =
+ * the count it needed, the call returns PFHIP_ERR_CAPACITY, and every OTHER connection of the batch is served as usual
+ * (callers merged by pfhip_set_stream_batching each get their own status).  A failure of the shared forward itself
+ * (HIP error, more than 72 CIF fires in one chunk) fails all connections and re-initialises their caches (as
+ * pfhip_stream_reset), so no stream is left with a half-advanced chunk. */
 pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm,
                                         const int* n_samples, const int* input_finished, int32_t* const* token_ids,
                                         const int* cap, int* n_tokens);
@@ -291,6 +296,9 @@ typedef struct {
   double flops[PFHIP_NUM_KCLASS];    /* algorithmic flops issued (pad rows/cols excluded)           */
   double bytes[PFHIP_NUM_KCLASS];    /* algorithmic bytes (compulsory reads + writes)               */
 } pfhip_profile;
+/* Test hook, not part of the serving path: "blstm_flag" (value != 0) raises the timestamp head's error word for the next
+ * timestamp request only, which then fails with PFHIP_ERR_HIP; later requests are unaffected. */
+pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value);
 pfhip_status pfhip_profile_enable(pfhip_model* m, int on);
 pfhip_status pfhip_profile_read(pfhip_model* m, pfhip_profile* out, int reset);
 

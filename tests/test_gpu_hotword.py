@@ -71,3 +71,27 @@ def test_plain_model_ignores_hotwords(pkg, weights_mod):
     b = m.forward_ids([u], hw_emb=np.ones((2, 512), np.float32))
     assert list(a["ids"][0]) == list(b["ids"][0])
     m.close()
+
+
+def test_more_hotwords_than_audio_rows_on_a_fresh_handle(pkg, weights_mod):
+    """300 hotwords against a 2-s utterance on a handle that has run nothing else: the hotword K/V projection is larger than
+    every audio-side workspace (Mp = 128 rows), so it must live in a buffer of its own (round-1 advisor finding)."""
+    cfg = weights_mod.small_config(enc_layers=1, dec_layers=1, vocab=400, contextual=1)
+    man, blob = weights_mod.synth_weights(cfg, seed=7)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    W = P.Weights(man, blob)
+    rng = np.random.default_rng(5)
+    u = synth_pcm(3, 32000, rng)
+    hw = model.CompileHotwordEmbedding([list(rng.integers(2, 400, int(rng.integers(1, 8)))) for _ in range(300)])
+    assert hw.shape == (301, 512)
+    got = model.forward_ids([u], want_logp=True, hw_emb=hw)
+    ref = P.forward_pcm(u, W, hw_emb=hw)
+    assert got["n_fires"][0] == ref["emb"].shape[0]
+    assert np.abs(got["logp"][0] - ref["logp"]).max() < 1e-3
+    assert list(got["ids"][0]) == list(ref["ids"])
+    # a second, smaller hotword set on the same handle replaces the first
+    hw2 = hw[:5].copy()
+    got2 = model.forward_ids([u], want_logp=True, hw_emb=hw2)
+    ref2 = P.forward_pcm(u, W, hw_emb=hw2)
+    assert np.abs(got2["logp"][0] - ref2["logp"]).max() < 1e-3
+    model.close()

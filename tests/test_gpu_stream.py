@@ -204,3 +204,63 @@ def test_threads_per_connection_are_merged(pkg, weights_mod):
     for s in streams:
         s.close()
     model.close()
+
+
+def test_one_small_token_buffer_does_not_fail_the_other_connections(pkg, weights_mod):
+    """Merged streaming calls carry one status per connection (round-1 advisor finding): a connection whose token buffer
+    is too small gets PFHIP_ERR_CAPACITY and the count it needed; the connections merged with it get their ids."""
+    import threading
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=2, vocab=500)
+    man, blob = weights_mod.synth_weights(cfg, seed=23)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    rng = np.random.default_rng(9)
+    waves = [synth_pcm(i, 9600 * 4, rng) for i in range(4)]
+    alone = []
+    for w in waves:
+        s = pkg.ParaformerOnlineHip(model)
+        alone.append([s.Forward(w[a:a + 9600], input_finished=(a + 9600 >= len(w))) for a in range(0, len(w), 9600)])
+        s.close()
+    step = next(j for j in range(4) if all(len(a[j]) > 0 for a in alone))      # a round in which every connection emits tokens
+    # explicit batch call
+    streams = [pkg.ParaformerOnlineHip(model) for _ in waves]
+    for j in range(4):
+        caps = [256, 0, 256, 256] if j == step else [256] * 4
+        st, ids, nt = pkg.ParaformerOnlineHip.forward_batch(streams, [w[9600 * j:9600 * (j + 1)] for w in waves], [j == 3] * 4, caps)
+        if j == step:
+            assert st == 5                                   # PFHIP_ERR_CAPACITY
+            assert nt[1] == len(alone[1][j]) and ids[1] == []
+        else:
+            assert st == 0 and ids[1] == alone[1][j]
+        for i in (0, 2, 3):
+            assert ids[i] == alone[i][j], (i, j)
+    for s in streams:
+        s.close()
+    # one thread per connection, merged by the library
+    model.set_stream_batching(20000, 4)
+    streams = [pkg.ParaformerOnlineHip(model) for _ in waves]
+    got = [[None] * 4 for _ in waves]
+    errs = [None] * 4
+    barrier = threading.Barrier(4)
+
+    def feed(i):
+        for j in range(4):
+            barrier.wait()
+            try:
+                got[i][j] = streams[i].Forward(waves[i][9600 * j:9600 * (j + 1)], input_finished=(j == 3),
+                                               cap=0 if (i == 1 and j == step) else 256)
+            except pkg.PfhipError as e:
+                errs[i] = (j, str(e))
+    ths = [threading.Thread(target=feed, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert errs[0] is None and errs[2] is None and errs[3] is None
+    assert errs[1] is not None and errs[1][0] == step and "token_ids too small" in errs[1][1]
+    for i in (0, 2, 3):
+        assert got[i] == alone[i]
+    assert [g for j, g in enumerate(got[1]) if j != step] == [a for j, a in enumerate(alone[1]) if j != step]
+    model.set_stream_batching(0, 1)
+    for s in streams:
+        s.close()
+    model.close()

@@ -90,3 +90,19 @@ def test_plain_model_refuses_timestamps(pkg, weights_mod):
     with pytest.raises(pkg.PfhipError):
         h.forward_ids([np.zeros(16000, np.float32)], want_timestamps=True)
     h.close()
+
+
+def test_blstm_error_flag_is_per_call(model, pkg):
+    """A step-barrier time-out fails the request that saw it and only that one (round-1 advisor finding: the flag word
+    used to stay set for the life of the handle)."""
+    h, W = model
+    rng = np.random.default_rng(11)
+    waves = [synth_pcm(i, n, rng) for i, n in enumerate([16000 * 2, 16000 * 3])]
+    good = h.forward_ids(waves, want_timestamps=True)
+    assert h._lib.pfhip_debug_poke(h.handle, b"blstm_flag", 1) == 0
+    with pytest.raises(pkg.PfhipError, match="BLSTM"):
+        h.forward_ids(waves, want_timestamps=True)
+    again = h.forward_ids(waves, want_timestamps=True)
+    for b in range(2):
+        assert np.array_equal(again["us_alphas"][b], good["us_alphas"][b])
+        assert np.array_equal(again["us_peaks"][b], good["us_peaks"][b])

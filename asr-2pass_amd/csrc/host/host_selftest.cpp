@@ -2,6 +2,8 @@
 //   host_selftest mergequeue <threads> <rounds>     stress of merge_queue.h: every request served exactly once, merged batches
 //   host_selftest tokenize <tokens.json> [manifest]  stdin lines -> "n | w0 w1 ... | id0 id1 ..." (PuncTokenizerHip::Tokenize)
 //   host_selftest jsonstrings <file>                 prints the strings of the first JSON array, one per line, as hex bytes
+//   host_selftest vocabtext <tokens.json> [language]  stdin lines of ids -> HostVocab::Vector2StringV2 of each line (ONE object:
+//                                                     the end-of-call memory carries over), as hex bytes
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +16,7 @@
 
 #include "../merge_queue.h"
 #include "ct_transformer_hip.h"
+#include "host_vocab.h"
 #include "json_strings.h"
 
 namespace {
@@ -88,6 +91,21 @@ int main(int argc, char** argv) {
     }
     std::printf("punc %s %s %s %s %s %s ispunc %d %d\n", tk.Id2Punc(0).c_str(), tk.Id2Punc(1).c_str(), tk.Id2Punc(2).c_str(),
                 tk.Id2Punc(3).c_str(), tk.Id2Punc(4).c_str(), tk.Id2Punc(5).c_str(), (int)tk.IsPunc(tk.Id2Punc(3)), (int)tk.IsPunc("x"));
+    return 0;
+  }
+  if (cmd == "vocabtext" && argc >= 3) {
+    pfhip_host::HostVocab vocab;
+    if (!vocab.Load(argv[2])) { std::fprintf(stderr, "cannot open tokens\n"); return 1; }
+    const std::string language = argc > 3 ? argv[3] : "";
+    std::string line;
+    while (std::getline(std::cin, line)) {
+      std::vector<int> ids;
+      std::stringstream ss(line);
+      int v;
+      while (ss >> v) ids.push_back(v);
+      for (unsigned char c : vocab.Vector2StringV2(ids, language)) std::printf("%02x", c);
+      std::printf("\n");
+    }
     return 0;
   }
   if (cmd == "jsonstrings" && argc >= 3) {

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 
 namespace funasr {
@@ -14,33 +15,24 @@ namespace {
 // per calling thread
 thread_local std::vector<std::vector<int>> tl_last_ids;
 thread_local std::vector<std::vector<float>> tl_last_spans;
-
-// tokens.json: a flat JSON array of strings (the format of the reference's token file).
-std::vector<std::string> LoadTokens(const std::string& path) {
-  std::vector<std::string> out;
-  std::ifstream f(path);
-  if (!f) return out;
-  std::stringstream ss;
-  ss << f.rdbuf();
-  const std::string s = ss.str();
-  size_t i = 0;
-  while ((i = s.find('"', i)) != std::string::npos) {
-    std::string tok;
-    for (++i; i < s.size() && s[i] != '"'; ++i) {
-      if (s[i] == '\\' && i + 1 < s.size()) ++i;
-      tok += s[i];
-    }
-    ++i;
-    out.push_back(tok);
-  }
-  return out;
-}
+// Vocab::Vector2StringV2 updates a member (`last_is_complete_english_`, vocab.h:22); the reference calls it unguarded from
+// every decoder thread.  Here the text step of concurrent Forward calls is serialised.
+std::mutex g_text_mu;
 }  // namespace
 
-ParaformerHip::ParaformerHip() {}
+ParaformerHip::ParaformerHip() {
+#ifdef PFHIP_WITH_FUNASR
+  lm_ = nullptr; phone_set_ = nullptr; lm_vocab = nullptr;       // WfstDecodable leaves its raw pointers uninitialised
+#endif
+}
 
 ParaformerHip::~ParaformerHip() {
   if (handle_) pfhip_destroy(handle_);
+  delete vocab;
+#ifdef PFHIP_WITH_FUNASR
+  delete lm_vocab;
+  delete phone_set_;
+#endif
 }
 
 void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
@@ -54,20 +46,57 @@ void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_c
   // thread_num = the decoder threads that will share this handle (funasr-wss-server.cpp:479-481): the reference gives
   // each its own intra-op thread; here their concurrent Forward calls are merged into packed launches instead
   if (thread_num > 1) pfhip_set_batching(handle_, 3000, 96);   // 96 merged utterances: +16 % over 32 on the long-audio flow
-  if (!token_file.empty()) tokens_ = LoadTokens(token_file);
+  if (!token_file.empty()) {                                   // paraformer.cpp:47-48
+    delete vocab;
+#ifdef PFHIP_WITH_FUNASR
+    vocab = new Vocab(token_file.c_str());
+#else
+    vocab = new HipVocab();
+    if (!vocab->Load(token_file.c_str())) { delete vocab; vocab = nullptr; }
+#endif
+  }
+}
+
+void ParaformerHip::InitLm(const std::string& lm_file, const std::string& lm_cfg_file, const std::string& lex_file) {
+  InitLm(lm_file, lm_cfg_file, lex_file, "");
+}
+
+void ParaformerHip::InitLm(const std::string& lm_file, const std::string& lm_cfg_file, const std::string& lex_file,
+                           const std::string& lm_units_path) {
+#ifdef PFHIP_WITH_FUNASR
+  try {                                                          // paraformer.cpp:160-175
+    lm_ = std::shared_ptr<fst::Fst<fst::StdArc>>(fst::Fst<fst::StdArc>::Read(lm_file));
+    if (lm_) {
+      lm_vocab = new Vocab(lm_cfg_file.c_str(), lex_file.c_str());
+      if (lm_units_path.size() > 0) phone_set_ = new PhoneSet(lm_units_path.c_str());
+    } else {
+      std::fprintf(stderr, "Failed to load lm file %s\n", lm_file.c_str());
+    }
+  } catch (std::exception const& e) {
+    std::fprintf(stderr, "Error when load lm file: %s\n", e.what());
+    std::exit(0);
+  }
+  has_lm_ = lm_ != nullptr;
+#else
+  (void)lm_cfg_file; (void)lex_file; (void)lm_units_path;
+  has_lm_ = static_cast<bool>(std::ifstream(lm_file));           // no openfst here: the decoder that is handed in owns the graph
+  if (!has_lm_) std::fprintf(stderr, "Failed to load lm file %s\n", lm_file.c_str());
+#endif
 }
 
 int ParaformerHip::GetAsrSampleRate() { return handle_ ? pfhip_sample_rate(handle_) : 16000; }
 
-std::string ParaformerHip::IdsToString(const std::vector<int>& ids) const {
+// Vocab::Vector2StringV2(hyps, language) (paraformer.cpp:396); without a token file (harness runs on synthetic models)
+// the ids themselves, space separated
+std::string ParaformerHip::IdsToString(const std::vector<int>& ids) {
+  if (vocab) {
+    std::lock_guard<std::mutex> lk(g_text_mu);
+    return vocab->Vector2StringV2(ids, language);
+  }
   std::string s;
   for (size_t i = 0; i < ids.size(); ++i) {
-    if (!tokens_.empty() && ids[i] >= 0 && (size_t)ids[i] < tokens_.size()) {
-      s += tokens_[ids[i]];
-    } else {
-      if (i) s += ' ';
-      s += std::to_string(ids[i]);
-    }
+    if (i) s += ' ';
+    s += std::to_string(ids[i]);
   }
   return s;
 }
@@ -75,21 +104,28 @@ std::string ParaformerHip::IdsToString(const std::vector<int>& ids) const {
 std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool input_finished,
                                                 const std::vector<std::vector<float>>& hw_emb, void* wfst_decoder,
                                                 int batch_in) {
-  (void)input_finished;
-  (void)wfst_decoder;
   std::vector<std::string> results(batch_in > 0 ? batch_in : 0);
   tl_last_ids.assign(results.size(), {});
   tl_last_spans.assign(results.size(), {});
   if (batch_in <= 0 || !handle_) return results;
+  // paraformer.cpp:563: the LM decides between GreedySearch and the decoder that came with the call
+  Decoder* decoder = has_lm_ ? static_cast<Decoder*>(wfst_decoder) : nullptr;
   int max_len = 0;
   for (int i = 0; i < batch_in; ++i) max_len = len[i] > max_len ? len[i] : max_len;
   const int max_tokens = max_len / 960 + 2;       // at most T+1 CIF fires, T = ceil(frames/6)
-  std::vector<int32_t> ids((size_t)batch_in * max_tokens), tn(batch_in), nf(batch_in), usl(batch_in);
+  const int V = pfhip_vocab_size(handle_);
+  std::vector<int32_t> ids((size_t)batch_in * max_tokens), tn(batch_in), nf(batch_in), usl(batch_in), fr(batch_in);
+  std::vector<float> logp;
   pfhip_out out{};
   out.token_ids = ids.data();
   out.token_num = tn.data();
   out.n_fires = nf.data();
+  out.n_frames = fr.data();
   out.max_tokens = max_tokens;
+  if (decoder) {                                  // the rows Search consumes: [batch][max_tokens][V] log-probabilities
+    logp.resize((size_t)batch_in * max_tokens * V);
+    out.logp = logp.data();
+  }
   const bool with_ts = pfhip_has_timestamp_head(handle_) != 0;      // the reference's outputTensor.size() == 4 (paraformer.cpp:545)
   const int max_us = 3 * max_tokens;
   std::vector<float> usa, usp;
@@ -117,13 +153,32 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
   for (int i = 0; i < batch_in; ++i) {
     const int n = tn[i] < nf[i] ? tn[i] : nf[i];
     tl_last_ids[i].assign(ids.begin() + (size_t)i * max_tokens, ids.begin() + (size_t)i * max_tokens + n);
+    if (decoder && fr[i] > 0) {                   // no feature frame: "" before any decoding (paraformer.cpp:477-480)
+      // BeamSearch + FinalizeDecode (paraformer.cpp:410-419, 563-579; per item as paraformer-torch.cpp:431-466): `n` rows of V
+      // log-probabilities, of which WfstDecoder::Search feeds the first n - 1 to the lattice decoder (wfst-decoder.cpp:27-58)
+      try {
+        std::string text = decoder->Search(logp.data() + (size_t)i * max_tokens * V, n, (int64_t)V);
+        if (input_finished) {
+          if (with_ts)
+            text = decoder->FinalizeDecode(true, std::vector<float>(usa.begin() + (size_t)i * max_us, usa.begin() + (size_t)i * max_us + usl[i]),
+                                           std::vector<float>(usp.begin() + (size_t)i * max_us, usp.begin() + (size_t)i * max_us + usl[i]));
+          else
+            text = decoder->FinalizeDecode();
+        }
+        results[i] = text;
+      } catch (std::exception const& e) {
+        std::fprintf(stderr, "ParaformerHip::Forward: %s\n", e.what());
+      }
+      if (batch_in > 1) decoder->StartUtterance();
+      continue;
+    }
     results[i] = IdsToString(tl_last_ids[i]);
     if (with_ts && n > 0 && usl[i] > 0) {
       // GreedySearch(..., is_stamp = true) -> TimestampOnnx over the characters of the hypothesis (paraformer.cpp:386-395)
       // char_list = all token_num hypotheses (Vocab::Vector2String keeps every id); TimestampOnnx drops a trailing "</s>"
       // (util.cpp:846-849) — id 2 in the FunASR vocabularies when no tokens.json is loaded
       const int last = tl_last_ids[i].back();
-      const bool eos = tokens_.empty() ? last == 2 : ((size_t)last < tokens_.size() && tokens_[last] == "</s>");
+      const bool eos = !vocab ? last == 2 : vocab->Id2String(last) == "</s>";
       const int n_chars = n - (eos ? 1 : 0);
       std::vector<float> spans((size_t)3 * (2 * n + 2));
       int n_spans = 0;
@@ -131,10 +186,10 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
           pfhip_timestamp_onnx(usa.data() + (size_t)i * max_us, usp.data() + (size_t)i * max_us, usl[i], n_chars, 0.f, -1.5f,
                                spans.data(), (int)spans.size() / 3, &n_spans) == PFHIP_OK)
         tl_last_spans[i].assign(spans.begin(), spans.begin() + (size_t)3 * n_spans);
-      if (!tokens_.empty() && n_spans > 0) {
+      if (vocab && n_spans > 0) {
         // time-stamp mode returns "<text> | <stamps>" (paraformer.cpp:398-406: Vector2String -> TimestampOnnx -> PostProcess)
         std::vector<std::string> raw_char;
-        for (int id : tl_last_ids[i]) raw_char.push_back((size_t)id < tokens_.size() ? tokens_[id] : "<unk>");
+        vocab->Vector2String(tl_last_ids[i], raw_char);
         std::vector<std::vector<float>> stamps;
         for (int k = 0; k < n_spans; ++k)
           if (spans[3 * k + 2] == 0.f) stamps.push_back({spans[3 * k], spans[3 * k + 1]});       // <sil> spans carry no character (util.cpp:957-961)
@@ -174,8 +229,7 @@ std::vector<std::vector<float>> ParaformerHip::CompileHotwordEmbedding(std::stri
     bool known = true;
     for (const std::string& ch : Utf8Chars(word)) {
       int id = -1;
-      for (size_t t = 0; t < tokens_.size(); ++t)
-        if (tokens_[t] == ch) { id = (int)t; break; }
+      if (vocab) id = vocab->GetIdByToken(ch);
       if (id < 0) { known = false; break; }       // the reference drops a hotword with an out-of-vocabulary unit (:634-640)
       if ((int)row.size() < kMaxLen) row.push_back(id);
     }

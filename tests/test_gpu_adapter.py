@@ -92,6 +92,7 @@ def test_logprob_rows_reach_the_decoder(pkg, weights_mod, tmp_path, timestamp):
         assert ids[b] == list(want["ids"][b])
         text = v.vector2string_v2(ids[b], "zh-cn")
         if timestamp and ids[b]:
-            assert res[b].startswith("".join(vocab[i] for i in ids[b] if vocab[i] not in ("</s>",)).replace("<s>", "")[:1]) or " | " in res[b]
+            # time-stamp mode: "<text> | <stamps>" (PostProcess, util.cpp:733-835; compared in detail by test_timestamp.py)
+            assert res[b] == text or " | " in res[b]
         else:
             assert res[b] == text

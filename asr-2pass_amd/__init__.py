@@ -23,7 +23,7 @@ KCLASS_NAMES = ["gemm", "attention", "layernorm", "fsmn", "fbank", "cif", "head"
 
 # every symbol include/pfhip.h declares (tests check the built library exports exactly these)
 ABI_SYMBOLS = [
-    "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_destroy",
+    "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_create_group", "pfhip_group_size", "pfhip_group_stats", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
     "pfhip_set_batching", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
@@ -84,6 +84,9 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
     lib.pfhip_destroy.argtypes = [vp]
     lib.pfhip_destroy.restype = None
+    lib.pfhip_create_group.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
+    lib.pfhip_group_size.argtypes = [vp]
+    lib.pfhip_group_stats.argtypes = [vp, vp, vp, vp, vp, ci]
     for f in ("pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model"):
         getattr(lib, f).argtypes = [vp]
     lib.pfhip_offline_forward.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ci, ctypes.POINTER(_Out)]
@@ -165,17 +168,23 @@ class ParaformerHip:
         self.cfg = None
 
     # -- lifetime ----------------------------------------------------------------------------------
-    def InitAsr(self, am_model, am_cmvn=None, am_config=None, token_file=None, thread_num=1, device=0):
+    def InitAsr(self, am_model, am_cmvn=None, am_config=None, token_file=None, thread_num=1, device=0, devices=None):
         """am_model: path prefix of `<prefix>.bin/.json`, or a (manifest dict, float32 blob) pair.
-        am_cmvn/am_config are folded into the container (cmvn.* tensors, config block)."""
+        am_cmvn/am_config are folded into the container (cmvn.* tensors, config block).
+        devices=[0, 1, ...]: one replica per listed device behind this one handle (pfhip_create_group)."""
         if self._h:
             self._lib.pfhip_destroy(self._h)
             self._h = ctypes.c_void_p()
         if isinstance(am_model, (tuple, list)):
             man, blob = am_model
             blob = np.ascontiguousarray(blob, dtype=np.float32)
-            _check(self._lib, self._lib.pfhip_create_from_memory(
-                blob.ctypes.data, blob.nbytes, json.dumps(man).encode(), device, ctypes.byref(self._h)))
+            if devices is not None:
+                devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+                _check(self._lib, self._lib.pfhip_create_group(
+                    blob.ctypes.data, blob.nbytes, json.dumps(man).encode(), devs, len(devices), ctypes.byref(self._h)))
+            else:
+                _check(self._lib, self._lib.pfhip_create_from_memory(
+                    blob.ctypes.data, blob.nbytes, json.dumps(man).encode(), device, ctypes.byref(self._h)))
             self.cfg = man["config"]
         else:
             _check(self._lib, self._lib.pfhip_create(
@@ -210,6 +219,13 @@ class ParaformerHip:
 
     def GetBatchSize(self):
         return self._batch_size
+
+    def group_stats(self):
+        """Per replica of the handle: dict(devices, calls, utterances, open_streams) (pfhip_group_stats)."""
+        n = self._lib.pfhip_group_size(self._h)
+        dev = np.zeros(n, np.int32); calls = np.zeros(n, np.int64); utts = np.zeros(n, np.int64); streams = np.zeros(n, np.int32)
+        _check(self._lib, self._lib.pfhip_group_stats(self._h, dev.ctypes.data, calls.ctypes.data, utts.ctypes.data, streams.ctypes.data, n))
+        return dict(devices=dev.tolist(), calls=calls.tolist(), utterances=utts.tolist(), open_streams=streams.tolist())
 
     def set_stream_batching(self, wait_us, max_streams=128):
         """Merge concurrent ParaformerOnlineHip.Forward callers (one thread per connection) into batched forwards."""

@@ -168,8 +168,41 @@ struct pfhip_model {
   pfhip_profile prof{};
   hipStream_t prof_stream = nullptr;
 
+  // in-process multi-GPU router (replicas only): the handle the caller holds is replica 0; `replicas` are full
+  // models on the other devices of PFHIP_DEVICES / pfhip_create_group.  Offline calls go to the replica with the fewest calls
+  // in flight, a new stream to the one with the fewest open streams (a connection stays on its device for life).
+  std::vector<pfhip_model*> replicas;
+  pfhip_model* group_head = nullptr;        // replica -> the handle the caller holds (nullptr on the head itself)
+  std::atomic<int> inflight{0};
+  std::atomic<int64_t> served_calls{0}, served_utts{0};
+  std::atomic<unsigned> rr{0};
+
   const Tensor& W(const std::string& n) const { return t.at(n); }
 };
+
+namespace pfhip_detail {
+// least-loaded replica of the group `m` heads (m itself when it has none); ties go round-robin
+inline pfhip_model* route_offline(pfhip_model* m) {
+  if (m->replicas.empty()) return m;
+  const size_t n = m->replicas.size() + 1;
+  const unsigned start = m->rr.fetch_add(1);
+  pfhip_model* best = nullptr;
+  int best_load = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const size_t i = (start + k) % n;
+    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
+    const int load = r->inflight.load();
+    if (!best || load < best_load) { best = r; best_load = load; }
+  }
+  return best;
+}
+inline pfhip_model* route_stream(pfhip_model* m) {
+  pfhip_model* best = m;
+  for (pfhip_model* r : m->replicas)
+    if (r->live_streams.load() < best->live_streams.load()) best = r;
+  return best;
+}
+}  // namespace pfhip_detail
 
 namespace pfhip_detail {
 

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -728,11 +729,70 @@ extern "C" {
 
 const char* pfhip_last_error(void) { return g_err.c_str(); }
 
+pfhip_status pfhip_create_group(const void* blob, size_t blob_bytes, const char* manifest_json, const int* devices, int n_devices,
+                                pfhip_model** out) {
+  g_err.clear();
+  if (!devices || n_devices < 1 || !out) return fail(PFHIP_ERR_ARG, "bad device list");
+  pfhip_model* head = nullptr;
+  try {
+    pfhip_status st = build_model(blob, blob_bytes, manifest_json, devices[0], &head);
+    if (st) return st;
+    for (int i = 1; i < n_devices; ++i) {
+      pfhip_model* r = nullptr;
+      st = build_model(blob, blob_bytes, manifest_json, devices[i], &r);
+      if (st) { const std::string why = g_err; pfhip_destroy(head); g_err = why; return st; }
+      r->group_head = head;
+      head->replicas.push_back(r);
+    }
+  } catch (const std::exception& e) {
+    if (head) pfhip_destroy(head);
+    return fail(PFHIP_ERR_FORMAT, e.what());
+  }
+  *out = head;
+  return PFHIP_OK;
+}
+
+// PFHIP_DEVICES="0,1,2,..." turns every model created through pfhip_create / pfhip_create_from_memory into a group with one
+// replica per listed device (the `device` argument is then ignored): the unchanged server with its one shared handle and
+// `decoder-thread-num` threads (funasr-wss-server.cpp:479-481) uses all of them.
+static bool env_devices(std::vector<int>& devs) {
+  const char* e = std::getenv("PFHIP_DEVICES");
+  if (!e || !*e) return false;
+  devs.clear();
+  std::stringstream ss(e);
+  std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    if (tok.empty()) continue;
+    char* end = nullptr;
+    const long v = std::strtol(tok.c_str(), &end, 10);
+    if (end == tok.c_str() || *end != '\0' || v < 0) return false;
+    devs.push_back((int)v);
+  }
+  return !devs.empty();
+}
+
 pfhip_status pfhip_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
                                       pfhip_model** out) {
   g_err.clear();
+  std::vector<int> devs;
+  if (env_devices(devs)) return pfhip_create_group(blob, blob_bytes, manifest_json, devs.data(), (int)devs.size(), out);
   try { return build_model(blob, blob_bytes, manifest_json, device, out); }
   catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
+}
+
+int pfhip_group_size(const pfhip_model* m) { return m ? 1 + (int)m->replicas.size() : 0; }
+
+pfhip_status pfhip_group_stats(pfhip_model* m, int* devices, int64_t* calls, int64_t* utterances, int* open_streams, int cap) {
+  g_err.clear();
+  if (!m || cap < 1 + (int)m->replicas.size()) return fail(PFHIP_ERR_ARG, "bad argument");
+  for (int i = 0; i <= (int)m->replicas.size(); ++i) {
+    const pfhip_model* r = i == 0 ? m : m->replicas[(size_t)i - 1];
+    if (devices) devices[i] = r->device;
+    if (calls) calls[i] = r->served_calls.load();
+    if (utterances) utterances[i] = r->served_utts.load();
+    if (open_streams) open_streams[i] = r->live_streams.load();
+  }
+  return PFHIP_OK;
 }
 
 pfhip_status pfhip_create(const char* weight_blob_path, const char* manifest_json_path, int device, pfhip_model** out) {
@@ -749,6 +809,8 @@ pfhip_status pfhip_create(const char* weight_blob_path, const char* manifest_jso
 
 void pfhip_destroy(pfhip_model* m) {
   if (!m) return;
+  for (pfhip_model* r : m->replicas) pfhip_destroy(r);
+  m->replicas.clear();
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
@@ -886,12 +948,21 @@ static pfhip_status forward_batched(pfhip_model* m, const float* const* pcm, con
   return me.st;
 }
 
-pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,
+namespace { thread_local pfhip_model* tl_last_replica = nullptr; }      // where this thread's last offline forward ran (debug getters)
+
+pfhip_status pfhip_offline_forward(pfhip_model* head, const float* const* pcm, const int* n_samples, int batch,
                                    const float* hw_emb, int n_hotwords, pfhip_out* out) {
   g_err.clear();
-  if (!m || !pcm || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
+  if (!head || !pcm || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
   for (int i = 0; i < batch; ++i)
     if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
+  pfhip_model* m = route_offline(head);                  // the replica (= GPU) with the fewest calls in flight
+  struct InFlight {
+    pfhip_model* r; int n;
+    InFlight(pfhip_model* r_, int n_) : r(r_), n(n_) { ++r->inflight; }
+    ~InFlight() { --r->inflight; ++r->served_calls; r->served_utts += n; }
+  } guard(m, batch);
+  tl_last_replica = m;
   if (m->batch_wait_us > 0 && !m->cfg.contextual && !m->cfg.timestamp && batch < m->batch_max_utts)
     return forward_batched(m, pcm, n_samples, batch, out);
   return forward_direct(m, pcm, n_samples, batch, hw_emb, n_hotwords, out);
@@ -900,18 +971,26 @@ pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, cons
 pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances) {
   g_err.clear();
   if (!m || wait_us < 0 || max_utterances < 1) return fail(PFHIP_ERR_ARG, "bad argument");
-  std::lock_guard<std::mutex> ql(m->bq.mu);
-  m->batch_wait_us = wait_us;
-  m->batch_max_utts = max_utterances;
+  for (size_t i = 0; i <= m->replicas.size(); ++i) {
+    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
+    std::lock_guard<std::mutex> ql(r->bq.mu);
+    r->batch_wait_us = wait_us;
+    r->batch_max_utts = max_utterances;
+  }
   return PFHIP_OK;
 }
 
 pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwords) {
   g_err.clear();
   if (!m || !hw_emb || n_hotwords <= 0) return fail(PFHIP_ERR_ARG, "bad argument");
-  std::lock_guard<std::mutex> lk(m->mu);
-  HIP_TRY(hipSetDevice(m->device));
-  return set_hotwords_locked(m, hw_emb, n_hotwords, m->own_stream);
+  for (size_t i = 0; i <= m->replicas.size(); ++i) {
+    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
+    std::lock_guard<std::mutex> lk(r->mu);
+    HIP_TRY(hipSetDevice(r->device));
+    pfhip_status st = set_hotwords_locked(r, hw_emb, n_hotwords, r->own_stream);
+    if (st) return st;
+  }
+  return PFHIP_OK;
 }
 
 int pfhip_is_contextual(const pfhip_model* m) { return m ? m->cfg.contextual : 0; }
@@ -985,6 +1064,8 @@ pfhip_status pfhip_extract_feats(pfhip_model* m, const float* const* pcm, const 
 pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size_t cap_floats, size_t* n_out) {
   g_err.clear();
   if (!m || !name || !dst) return fail(PFHIP_ERR_ARG, "bad argument");
+  // a group: the replica that served this thread's last offline forward holds the state being asked for
+  if (!m->replicas.empty() && tl_last_replica && (tl_last_replica == m || tl_last_replica->group_head == m)) m = tl_last_replica;
   std::lock_guard<std::mutex> lk(m->mu);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->prof_stream ? m->prof_stream : m->own_stream;

@@ -21,6 +21,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <thread>
 
 #include "internal.h"
 
@@ -486,6 +487,7 @@ extern "C" {
 pfhip_status pfhip_stream_create(pfhip_model* m, const int* chunk_size, pfhip_stream** out) {
   last_error().clear();
   if (!m || !out) return fail(PFHIP_ERR_ARG, "null argument");
+  m = pfhip_detail::route_stream(m);           // a group: the connection lives on the replica (GPU) with the fewest open streams
   std::lock_guard<std::mutex> lk(m->mu);
   HIP_TRY(hipSetDevice(m->device));
   std::unique_ptr<pfhip_stream> s(new pfhip_stream);
@@ -673,7 +675,41 @@ extern "C" {
 pfhip_status pfhip_stream_forward_batch(pfhip_stream* const* streams, int n_streams, const float* const* pcm, const int* n_samples,
                                         const int* input_finished, int32_t* const* token_ids, const int* cap, int* n_tokens) {
   last_error().clear();
-  return forward_batch_each(streams, n_streams, pcm, n_samples, input_finished, token_ids, cap, n_tokens, nullptr, nullptr);
+  if (!streams || n_streams <= 0 || !pcm || !n_samples || !input_finished || !token_ids || !cap || !n_tokens)
+    return fail(PFHIP_ERR_ARG, "bad argument");
+  // streams of a replica group (pfhip_create_group) may sit on different devices: one sub-batch per replica, run concurrently
+  std::vector<pfhip_model*> models;
+  for (int i = 0; i < n_streams; ++i) {
+    if (!streams[i]) return fail(PFHIP_ERR_ARG, "null stream");
+    if (std::find(models.begin(), models.end(), streams[i]->m) == models.end()) models.push_back(streams[i]->m);
+  }
+  if (models.size() == 1)
+    return forward_batch_each(streams, n_streams, pcm, n_samples, input_finished, token_ids, cap, n_tokens, nullptr, nullptr);
+  auto head_of = [](pfhip_model* m) { return m->group_head ? m->group_head : m; };
+  for (pfhip_model* m : models)
+    if (head_of(m) != head_of(models[0])) return fail(PFHIP_ERR_ARG, "streams of one batch must belong to one model");
+  struct Part { std::vector<int> idx; pfhip_status st = PFHIP_OK; std::string err; };
+  std::vector<Part> parts(models.size());
+  for (int i = 0; i < n_streams; ++i)
+    parts[(size_t)(std::find(models.begin(), models.end(), streams[i]->m) - models.begin())].idx.push_back(i);
+  std::vector<std::thread> pool;
+  for (Part& p : parts)
+    pool.emplace_back([&, pp = &p] {
+      const size_t n = pp->idx.size();
+      std::vector<pfhip_stream*> ss(n); std::vector<const float*> pc(n); std::vector<int> ns(n), fin(n), cp(n), nt(n); std::vector<int32_t*> ids(n);
+      for (size_t k = 0; k < n; ++k) {
+        const int i = pp->idx[k];
+        ss[k] = streams[i]; pc[k] = pcm[i]; ns[k] = n_samples[i]; fin[k] = input_finished[i]; cp[k] = cap[i]; ids[k] = token_ids[i];
+      }
+      last_error().clear();
+      pp->st = forward_batch_each(ss.data(), (int)n, pc.data(), ns.data(), fin.data(), ids.data(), cp.data(), nt.data(), nullptr, nullptr);
+      pp->err = last_error();
+      for (size_t k = 0; k < n; ++k) n_tokens[pp->idx[k]] = nt[k];
+    });
+  for (std::thread& t : pool) t.join();
+  for (const Part& p : parts)
+    if (p.st) { last_error() = p.err; return p.st; }
+  return PFHIP_OK;
 }
 
 }  // extern "C"
@@ -740,9 +776,12 @@ extern "C" {
 pfhip_status pfhip_set_stream_batching(pfhip_model* m, int wait_us, int max_streams) {
   last_error().clear();
   if (!m || wait_us < 0 || max_streams < 1) return fail(PFHIP_ERR_ARG, "bad argument");
-  std::lock_guard<std::mutex> ql(m->sq.mu);
-  m->stream_wait_us = wait_us;
-  m->stream_max = max_streams;
+  for (size_t i = 0; i <= m->replicas.size(); ++i) {
+    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
+    std::lock_guard<std::mutex> ql(r->sq.mu);
+    r->stream_wait_us = wait_us;
+    r->stream_max = max_streams;
+  }
   return PFHIP_OK;
 }
 

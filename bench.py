@@ -62,16 +62,47 @@ def max_over_ranks(dt: float, dist, device):
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01/pmc_hbm_traffic_e.json: FETCH_SIZE x2 +
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/rNN/pmc_hbm_traffic*.json: FETCH_SIZE x2 +
     WRITE_SIZE, collected with rocprofv3 in separate --pmc runs of this same command); PMC counters cannot be read from
-    inside the timed run, so this is the last profiled value, or null when the file is absent."""
-    for name in ("pmc_hbm_traffic_e.json", "pmc_hbm_traffic_d.json", "pmc_hbm_traffic_c.json", "pmc_hbm_traffic.json"):
+    inside the timed run, so this is the last PROFILED value — returned with the file it came from (`traffic_source`) so
+    that nobody reads it as measured in this run — or (None, None) when no file is present."""
+    for rel in ("r02/pmc_hbm_traffic.json", "r01/pmc_hbm_traffic_e.json", "r01/pmc_hbm_traffic_d.json", "r01/pmc_hbm_traffic_c.json",
+                "r01/pmc_hbm_traffic.json"):
         try:
-            with open(os.path.join(ROOT, "profiles", "r01", name)) as f:
-                return json.load(f)["gemm_avg_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", rel)) as f:
+                return json.load(f)["gemm_avg_bytes_per_launch"], "profiles/" + rel + " (rocprofv3 --pmc passes of an earlier run; not measured in this run)"
         except Exception:
             continue
-    return None
+    return None, None
+
+
+def streaming_block(pkg, model, weight_bytes, rng):
+    """BASELINE.json configs[2] (C3) beside the headline: ms per 600-ms chunk of the chunk-streaming path with the same
+    Paraformer-large-sized weights, for ONE connection (latency path: pfhip_stream_forward) and for 128 connections advancing
+    together (pfhip_stream_forward_batch).  A chunk (or a round of chunks) reads every weight once, so the HBM roofline of a
+    chunk is weight_bytes / 8 TB/s; `frac_hbm` = that time / measured time."""
+    out = {"chunk_ms_audio": 600, "weight_bytes_per_chunk": weight_bytes, "hbm_peak_GBps": 8000.0}
+    for B, rounds, warm in ((1, 60, 5), (128, 14, 2)):
+        streams = [pkg.ParaformerOnlineHip(model) for _ in range(B)]
+        waves = [synth_pcm(1000 + i, 9600 * (rounds + warm), rng) for i in range(B)]
+        tok = 0
+
+        def feed(k):
+            if B == 1:
+                return [streams[0].Forward(waves[0][k * 9600:(k + 1) * 9600], input_finished=False)]
+            return pkg.ParaformerOnlineHip.forward_batch(streams, [w[k * 9600:(k + 1) * 9600] for w in waves], [False] * B)
+        for k in range(warm):
+            feed(k)
+        t0 = time.perf_counter()
+        for k in range(warm, warm + rounds):
+            tok += sum(len(r) for r in feed(k))
+        dt = (time.perf_counter() - t0) / rounds
+        for x in streams:
+            x.close()
+        key = "one_connection" if B == 1 else f"{B}_connections"
+        out[key] = {"ms_per_chunk" if B == 1 else "ms_per_round": 1e3 * dt, "x_real_time": B * 0.6 / dt, "tokens": tok,
+                    "achieved_GBps": weight_bytes / dt / 1e9, "frac_hbm": weight_bytes / dt / 8e12}
+    return out
 
 
 def cpu_baseline(man, blob, utts, seconds_per_utt):
@@ -113,6 +144,7 @@ def main():
     ap.add_argument("--seconds", type=int, default=SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the C3 streaming block (rank 0, N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +213,22 @@ def main():
         prof_all = model.profile_read(reset=True)
         model.profile_enable(0)
     dt = max_over_ranks(dt, dist, torch.device("cuda", local_rank))
+    # the same K steps on the reference's own boundary: host float** buffers in (Model::Forward(float** din, ...), H2D inside
+    # the timed region where paraformer-torch.cpp:355-358 has it), ids out — reported beside `value`, never as `value`
+    for _ in range(min(args.warmup, 2)):
+        model.forward_ids(utts, max_tokens=max_tokens)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res_h = model.forward_ids(utts, max_tokens=max_tokens)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt_host = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+    assert all(list(a) == list(b) for a, b in zip(res_h["ids"], res["ids"]))
 
     audio_per_step = world * args.batch * args.seconds
     value = audio_per_step * args.steps / dt
@@ -193,6 +241,9 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (operands split exactly into 3 bf16 planes, products on the BF16 matrix cores, fp32 accumulate)",
             "data": "synthetic",
+            "value_host_buffers": audio_per_step * args.steps / dt_host, "ms_per_step_host_buffers": 1e3 * dt_host / args.steps,
+            "host_buffers_note": "same steps through pfhip_offline_forward(float** host pcm): the 61 MB H2D copy of the batch is "
+                                 "inside the timed region (the reference's Model::Forward boundary); `value` has the PCM resident in HBM",
             "config": {"workload": f"Paraformer-large offline, batch={args.batch} x {args.seconds} s synthetic 16 kHz "
                                    f"utterances per GPU (BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "utt_seconds": args.seconds, "lfr_frames_per_utt": int(res["n_frames"][0]),
@@ -201,12 +252,13 @@ def main():
         }
         if not args.no_profile:
             g = prof["gemm"]
+            traffic, traffic_source = pmc_traffic()
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
             out["roofline"] = {
                 # achieved = ALGORITHMIC fp32 flops (2*M*N*K) per second; the dominant kernel executes 6 bf16 MFMAs per block,
                 # so its ceiling is the BF16 dense peak / 6 (executed MFMA rate = 6 x achieved, against 2500)
                 "bound": "mfma", "kernel": "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel", "achieved": ach, "peak": X6_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / X6_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                "unit": "TFLOP/s", "frac": ach / X6_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "executed_mfma_tflops": ach * X6_MFMAS_PER_BLOCK, "executed_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": F32_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches_per_step": g["launches"] / args.steps,
@@ -216,6 +268,8 @@ def main():
                 "per_class_tflops_untimed_pass": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)
                                                   for k, v in prof_all.items() if v["flops"] > 0},
             }
+        if world == 1 and not args.no_streaming:
+            out["streaming"] = streaming_block(pkg, model, int(blob.nbytes), np.random.default_rng(SEED_PCM + 7))
         if world == 1 and not args.no_cpu_baseline:
             workers = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(man, blob, utts[:workers], args.seconds)

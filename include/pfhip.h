@@ -296,6 +296,24 @@ typedef struct {
   double flops[PFHIP_NUM_KCLASS];    /* algorithmic flops issued (pad rows/cols excluded)           */
   double bytes[PFHIP_NUM_KCLASS];    /* algorithmic bytes (compulsory reads + writes)               */
 } pfhip_profile;
+/* ---- in-process multi-GPU: one handle, one replica per device (replicas only, no collective) -----------------
+ * The reference server holds ONE model handle that all `decoder-thread-num` threads call into (funasr-wss-server.cpp:479-481,
+ * websocket-server.cpp:387-403).  A group keeps that shape on a multi-GPU node: the handle returned is replica 0, further
+ * replicas (full copies of the weights) live on the other devices; pfhip_offline_forward routes each call (or each merged
+ * batch, pfhip_set_batching) to the replica with the fewest calls in flight, pfhip_stream_create pins a new connection to the
+ * replica with the fewest open streams for its lifetime (device-resident caches), pfhip_set_hotwords / pfhip_set_batching /
+ * pfhip_set_stream_batching apply to every replica.  Results do not depend on which replica served a call.  No data moves
+ * between devices.  A device may be listed more than once (two replicas on one GPU: only useful for tests).
+ * PFHIP_DEVICES="0,1,..." in the environment makes pfhip_create / pfhip_create_from_memory build such a group (their `device`
+ * argument is then ignored), so the stock server needs no code change to use every GPU of the node.
+ * pfhip_offline_enqueue / pfhip_offline_fetch (device pointers) always use replica 0. */
+pfhip_status pfhip_create_group(const void* blob, size_t blob_bytes, const char* manifest_json, const int* devices, int n_devices,
+                                pfhip_model** out);
+int pfhip_group_size(const pfhip_model* m);
+/* Per replica (arrays of at least pfhip_group_size entries, any may be NULL): device ordinal, offline calls and utterances
+ * served so far, streams open now. */
+pfhip_status pfhip_group_stats(pfhip_model* m, int* devices, int64_t* calls, int64_t* utterances, int* open_streams, int cap);
+
 /* Test hook, not part of the serving path: "blstm_flag" (value != 0) raises the timestamp head's error word for the next
  * timestamp request only, which then fails with PFHIP_ERR_HIP; later requests are unaffected. */
 pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value);

@@ -94,7 +94,7 @@ def test_c3_ten_minute_stream_one_connection(pkg, weights_mod):
     assert total_ids > 1500
     # rows are x*sqrt(512) (~22.6 x 2e-5 of fbank error) + PE; a position error of one frame, or of one fp32 ulp of the phase at
     # p = 10^4 (1e-3 rad), would exceed this
-    assert worst_chunk < 2e-3 and worst_late < 2e-3, (worst_chunk, worst_late)
+    assert worst_chunk < 5e-4 and worst_late < 5e-4, (worst_chunk, worst_late)
     print(f"stream window rows: max err {worst_chunk:.2e} (p >= 9000: {worst_late:.2e}), {total_ids} ids over {n_chunks} chunks")
     hip.close()
     model.close()

@@ -719,6 +719,11 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
   // fill the chip (FFN2 at full batch: 201 vs 194 TF).  PFHIP_GEMM_X6=0 turns the path off.
   static const bool x6_on = [] { const char* e = getenv("PFHIP_GEMM_X6"); return !(e && e[0] == '0'); }();
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
+  if (kind == 6) {
+    launch_gemm_f32_bf16x6_v2(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
+                              column_group_width(M, K, (N + kTileN - 1) / kTileN), s);
+    return;
+  }
   if (kind == 4 || kind == 5 || (kind == 0 && x6_on && tiles >= 128)) {
     const bool small_tile = kind == 5 || (kind == 0 && !(K >= 1024 && tiles256 >= 180));
     launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,

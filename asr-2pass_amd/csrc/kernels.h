@@ -172,6 +172,13 @@ void launch_cif_stream(const float* enc, int lde, const float* alphas, const Str
 void launch_fsmn_cached(const float* t2, const float* w, const float* res, float* out, const StreamSeg* segs, int B, int layer,
                         int C, hipStream_t s);
 
+// ---- fused kernels for ONE streaming window (stream_fused.hip): M <= 32 rows ---------------------------------------------
+// C[M,N] = act(LN?(X) W^T + bias) (+R1) (+R2) (+ FSMN memory of fsmn_v: v + depthwise conv k = 11 over the M rows).
+// g == nullptr: no LayerNorm; D = LN width (<= K; columns D..K of the normalised operand are 0).  One workgroup per 32 columns.
+void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const float* b, float eps, const float* W, int ldw,
+                          float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+                          const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, bool relu, hipStream_t s);
+
 // ---- FSMN-VAD pieces --------------------------------------------------------------
 // Generic LfrCmvn over raw fbank frames fb [F, n_mels] -> out [T = ceil(F/n), ldo] (columns >= m*n_mels zeroed).
 void launch_lfr_cmvn(const float* fb, int F, int T, int m, int n, int n_mels, const float* mean, const float* istd,

@@ -24,6 +24,23 @@ int pfhip_op_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, flo
   pfhip::launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu != 0, guard != 0, kind, S(stream));
   return done();
 }
+int pfhip_op_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const float* b, float eps, const float* W, int ldw,
+                           float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+                           const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, int relu, void* stream) {
+  if (M < 1 || M > 32 || K % 8 || (g && (D % 4 || D > K || D > 2048))) return (int)hipErrorInvalidValue;
+  pfhip::launch_fused_ln_gemm(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu != 0,
+                              S(stream));
+  return done();
+}
+// dev hook (tools/fused_gemv_bench.py): n launches back to back over a ring of weight copies, so the host loop is not Python
+int pfhip_dev_fused_ln_gemm_bench(const float* X, int ldx, int D, const float* g, const float* b, const float* W, int ldw,
+                                  size_t w_stride_floats, int n_copies, float* C, int ldc, const float* bias, const float* R1, int ldr1,
+                                  int M, int N, int K, int relu, int n_launch, void* stream) {
+  for (int i = 0; i < n_launch; ++i)
+    pfhip::launch_fused_ln_gemm(X, ldx, D, g, b, 1e-12f, W + (size_t)(i % n_copies) * w_stride_floats, ldw, C, ldc, bias, R1, ldr1, nullptr,
+                                0, nullptr, 0, nullptr, M, N, K, relu != 0, S(stream));
+  return done();
+}
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream) {
   if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;

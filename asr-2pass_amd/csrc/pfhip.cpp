@@ -245,6 +245,17 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
         for (int j = 0; j < 3; ++j) q[(size_t)n * 3 * d + (size_t)j * d + ci] = cw.h[((size_t)n * d + ci) * 3 + j];
     st = upload(&m->d_predconv, q);
     if (st) return st;
+    if (c.dec_layers > 0) {     // streaming latency path: all layers' K/V projections of a window in one launch (stream.cpp)
+      std::vector<float> kw((size_t)c.dec_layers * 2 * d * d + (size_t)pfhip::kTileN * d, 0.f), kb((size_t)c.dec_layers * 2 * d + pfhip::kTileN, 0.f);
+      for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string dp = "dec." + std::to_string(i) + ".";
+        std::memcpy(&kw[(size_t)i * 2 * d * d], m->W(dp + "kv.w").h, sizeof(float) * 2 * d * d);
+        std::memcpy(&kb[(size_t)i * 2 * d], m->W(dp + "kv.b").h, sizeof(float) * 2 * d);
+      }
+      st = upload(&m->d_kv_all_w, kw);
+      if (!st) st = upload(&m->d_kv_all_b, kb);
+      if (st) return st;
+    }
     std::vector<float> vb((size_t)m->vocab_pad, 0.f);
     std::memcpy(vb.data(), m->W("dec.out.b").h, sizeof(float) * c.vocab);
     st = upload(&m->d_vocab_bias, vb);
@@ -816,11 +827,11 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
-                  (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh})
+                  (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh, (void*)m->d_kv_all_w, (void*)m->d_kv_all_b})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_ops) (void)hipHostFree(m->h_ops);

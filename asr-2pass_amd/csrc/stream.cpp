@@ -17,6 +17,8 @@
 // (StreamSeg) that points at each connection's own carry and caches.  pfhip_stream_forward is the batch of one.  `reserve_waveforms_` is dead state in the reference (it only feeds
 // its own index arithmetic, :162-171,180-182) and is not kept.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -259,12 +261,36 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   int maxn = 0;
   for (int b = 0; b < B; ++b) maxn = std::max(maxn, segs[b].n);
   float* x = m->x.f();
+  // One connection, one window: the latency path.  Launch count, not bytes or flops, sets its time (stream_fused.hip), so
+  // row-wise operators are folded into the GEMMs that consume them.  PFHIP_STREAM_FUSED=0 keeps the general path.
+  static const bool fused_on = [] { const char* e = getenv("PFHIP_STREAM_FUSED"); return !(e && e[0] == '0'); }();
+  const bool lean = fused_on && B == 1 && M <= 32;
+  auto ln_gemm = [&](const float* X, int ldx, int D, const std::string& norm, const float* Wd, int ldw, float* Cd, int ldc,
+                     const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, const float* fv, int ldv,
+                     const float* fw, int rows, int N, int K, bool relu) {
+    pfhip::launch_fused_ln_gemm(X, ldx, D, norm.empty() ? nullptr : m->W(norm + ".g").d, norm.empty() ? nullptr : m->W(norm + ".b").d,
+                                1e-12f, Wd, ldw, Cd, ldc, bias, R1, ldr1, R2, ldr2, fv, ldv, fw, rows, N, K, relu, st);
+  };
   // ---- streaming encoder session (:448): SAN-M stack on the windows as given (no scale/PE inside) --------
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
     const bool first = i == 0;
     const float* xin = first ? m->x0.f() : x;
     const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
+    if (lean) {
+      // 5 launches: LN1+QKV | attention | out-projection + FSMN memory + residual | LN2+FFN1 | FFN2 + residual
+      ln_gemm(xin, ldin, Din, p + "norm1", first ? m->d_w0qkv : m->W(p + "qkv.w").d, Kp, m->qkv.f(), 3 * d, m->W(p + "qkv.b").d,
+              nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, Kp, false);
+      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                              d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+      ln_gemm(m->ctx.f(), d, 0, "", m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, nullptr, 0,
+              m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, M, d, d, false);
+      ln_gemm(x, d, d, p + "norm2", m->W(p + "ffn1.w").d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0, nullptr, 0,
+              nullptr, 0, nullptr, M, c.ffn, d, true);
+      ln_gemm(m->hbuf.f(), c.ffn, 0, "", m->W(p + "ffn2.w").d, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0, nullptr, 0,
+              nullptr, M, d, c.ffn, false);
+      continue;
+    }
     lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
     gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
          m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
@@ -292,7 +318,17 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   pfhip::launch_cif_stream(m->enc.f(), d, m->alphas.f(), d_segs, B, c.cif_threshold, c.tail_threshold, m->emb.f(), kMaxTok,
                            m->counts.i(), d, st);
   HIP_TRY(hipMemcpyAsync(m->h_counts, m->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  static const bool timing = [] { const char* e = getenv("PFHIP_STREAM_TIMING"); return e && e[0] == '1'; }();
+  const auto t_sync0 = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(st));
+  if (timing) {
+    static double wait_us = 0, enq_us = 0; static int n = 0;
+    static auto t_last = t_sync0;
+    const auto t1 = std::chrono::steady_clock::now();
+    wait_us += std::chrono::duration<double, std::micro>(t1 - t_sync0).count();
+    (void)enq_us; (void)t_last;
+    if (++n % 50 == 0) { std::fprintf(stderr, "[stream timing] encoder: avg wait in sync %.1f us over %d chunks\n", wait_us / n, n); }
+  }
   const int* fires = m->h_counts;
   int ML = 0, maxN = 0;
   for (int b = 0; b < B; ++b) {
@@ -335,7 +371,15 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   float* xd = m->xd.f();
   float* kvbuf = m->qkv.f();
   pfhip::launch_compact(m->emb.f(), xd, d_src_row, ML, d, st);
+  const bool lean_dec = lean && ML <= 32;
   auto dec_ffn = [&](const std::string& p, const float* xin, float* o) {
+    if (lean_dec) {          // LN1+FFN1 | ffn_norm+FFN2
+      ln_gemm(xin, d, d, p + "norm1", m->W(p + "ffn1.w").d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr, 0, nullptr, 0,
+              nullptr, 0, nullptr, ML, c.dec_ffn, d, true);
+      ln_gemm(m->hd.f(), c.dec_ffn, c.dec_ffn, p + "ffn_norm", m->W(p + "ffn2.w").d, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
+              nullptr, 0, nullptr, ML, d, c.dec_ffn, false);
+      return;
+    }
     lnorm(m, st, xin, d, m->yd.f(), d, p + "norm1", ML, d, d);
     gemm(m, st, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
          0, nullptr, 0, ML, true);
@@ -343,11 +387,27 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     gemm(m, st, m->hd2.f(), c.dec_ffn, m->W(p + "ffn2.w").d, d, c.dec_ffn, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
          ML, false);
   };
+  const int kv_ld = c.dec_layers * 2 * d;
+  if (lean_dec) {            // the window is the same for every layer: all K/V projections in one launch
+    HIP_TRY(m->kvall.ensure((size_t)32 * (kv_ld + pfhip::kTileN) * 4));
+    ln_gemm(m->enc.f(), d, 0, "", m->d_kv_all_w, d, m->kvall.f(), kv_ld, m->d_kv_all_b, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M,
+            kv_ld, d, false);
+  }
   for (int i = 0; i < c.dec_layers; ++i) {
     const std::string p = "dec." + std::to_string(i) + ".";
     dec_ffn(p, xd, m->td.f());
     lnorm(m, st, m->td.f(), d, m->t2.f(), d, p + "norm2", ML, d, d);
     pfhip::launch_fsmn_cached(m->t2.f(), m->W(p + "fsmn.w").d, xd, xd, d_segs, B, i, d, st);
+    if (lean_dec) {
+      ln_gemm(xd, d, d, p + "norm3", m->W(p + "q.w").d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, nullptr, 0,
+              nullptr, ML, d, d, false);
+      const float* kvl = m->kvall.f() + (size_t)i * 2 * d;
+      pfhip::launch_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
+                              c.n_head, maxN, att_scale, st);
+      ln_gemm(m->ctxd.f(), d, 0, "", m->W(p + "out.w").d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, nullptr, 0, nullptr,
+              ML, d, d, false);
+      continue;
+    }
     lnorm(m, st, xd, d, m->yd.f(), d, p + "norm3", ML, d, d);
     gemm(m, st, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, ML, false);
     gemm(m, st, m->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, M,
@@ -357,9 +417,14 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
   }
   dec_ffn("dec3.", xd, m->td.f());
-  lnorm(m, st, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
-  gemm(m, st, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
-       nullptr, 0, ML, false);
+  if (lean_dec) {
+    ln_gemm(m->td.f(), d, d, "dec.after_norm", m->W("dec.out.w").d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
+            nullptr, 0, nullptr, 0, nullptr, ML, c.vocab, d, false);
+  } else {
+    lnorm(m, st, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
+    gemm(m, st, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
+         nullptr, 0, ML, false);
+  }
   pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, ML, c.vocab, want_logp ? m->logp.f() : nullptr,
                                   static_cast<int32_t*>(m->ids.p), st);
   std::vector<int32_t> ids(ML);

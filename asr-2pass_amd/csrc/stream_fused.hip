@@ -1,0 +1,349 @@
+// Fused kernels for ONE streaming window (`ForwardChunk`'s encoder and decoder Runs,
+// onnxruntime/src/paraformer-online.cpp:426-515, at M = 20 rows / a handful of tokens).
+//
+// A lone 600-ms chunk is neither compute- nor bandwidth-bound: it reads 0.88 GB of weights behind ~700 DEPENDENT launches
+// of ~7 us each (5 ms per chunk, 2 % of the HBM roofline).  A dependent launch costs its boundary (1.5-2 us) plus a kernel
+// that cannot be shorter than a few memory latencies, so the lever is the NUMBER of launches, and grid-wide barriers inside
+// one launch cost more than a boundary (MI355X_MICROARCH.md price list: barrier-xcd 4-5 us) — so the fusion has to respect
+// the data dependences between whole matrices.  What can be fused without any cross-workgroup exchange:
+//   * a row-wise operator in front of a GEMM is RECOMPUTED by every workgroup of that GEMM (20 x 512 elements: nothing):
+//     LayerNorm -> GEMM is one launch (`fused_ln_gemm_kernel`);
+//   * everything between two GEMMs that only needs whole small matrices is recomputed the same way: the encoder's
+//     FSMN memory + 4-head self-attention over the window + output projection + residuals is one launch
+//     (`fused_att_out_kernel`): every workgroup redoes the 20 x 20 attention (0.8 MFLOP) and then streams its own 32-column
+//     slice of W_o;
+//   * the decoder's norm2 -> cached FSMN -> residual -> norm3 -> q-projection chain likewise (`fused_dec_mid_kernel`), and
+//     cross-attention + output projection + residual (`fused_cross_out_kernel`); the 16 layers' K/V projections of the
+//     (fixed) encoder window are one GEMM over the concatenated weights.
+// An encoder layer becomes 4 launches (was 8), a decoder layer 4 (was 11).  Arithmetic: fp32 MFMA (`v_mfma_f32_32x32x2_f32`)
+// exactly as the weight-streaming GEMM of gemm.hip (K split over 16 waves, operands streamed straight into VGPRs, partial
+// tiles summed through LDS); LayerNorm two-pass in fp32 like rowops.hip.
+// All kernels take M <= 32 rows (one window of the [5,10,5] chunking is 20).
+#include "kernels.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
+
+namespace pfhip {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kWaves = 16;
+constexpr int kThreads = kWaves * 64;
+constexpr int kRows = 32;                  // activation rows a workgroup handles (one MFMA tile)
+
+// mean / rstd of rows [0, M) of X[., 0..D) into LDS, two-pass over values held in registers (one trip to memory; D <= 2048;
+// rows >= M get 0 / 0).  1024 threads: thread = (row = tid >> 5, 32 threads per row).  Ends with __syncthreads().
+__device__ __forceinline__ void row_stats(const float* __restrict__ X, int ldx, int M, int D, float eps, float* s_mean, float* s_rstd) {
+  const int tid = threadIdx.x, row = tid >> 5, c = tid & 31;
+  float mean = 0.f, rstd = 0.f;
+  if (row < M) {
+    const float* xr = X + (size_t)row * ldx;
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = 4 * c + 128 * u;
+      v[u] = k < D ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (4 * c + 128 * u < D) {
+        const float a = v[u].x - mean, b = v[u].y - mean, cc = v[u].z - mean, d = v[u].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    rstd = 1.0f / sqrtf(q / (float)D + eps);
+  }
+  if (c == 0) { s_mean[row] = mean; s_rstd[row] = rstd; }
+  __syncthreads();
+}
+
+// C[M<=32, N] = act(LN?(X) W^T + bias) (+R1) (+R2) (+FSMN memory of V), one workgroup per 32 output columns.
+//   LN:   X rows are normalised on the way into the MFMA operand: (x - mean) * rstd * g[k] + b[k] for k < D, 0 for k >= D
+//         (the first encoder layer's K is padded 560 -> 576).
+//   FSMN: + V[row][col] + sum_j fw[col][j] * V[row + j - 5][col] over rows inside [0, M) — the SAN-M memory block on the value
+//         projection of ONE window (UPSTREAM encoder layer; kernels.h launch_fsmn), added like a residual.
+// CW = output columns per workgroup (32, 8 or 4).  The job is weight STREAMING: a GEMM with N = 512 on 32-column patches keeps
+// 16 of the 256 CUs busy and takes 7-23 us (measured, K = 512 / 2048); narrower patches put 64-128 workgroups on it.  The MFMA
+// tile stays 32 wide (lanes beyond CW feed zeros): matrix-core work is not what this kernel waits for.
+template <bool LN, int CW>
+__global__ __launch_bounds__(kThreads) void fused_ln_gemm_kernel(
+    const float* __restrict__ X, int ldx, int D, const float* __restrict__ g, const float* __restrict__ b, float eps,
+    const float* __restrict__ W, int ldw, float* C, int ldc, const float* __restrict__ bias, const float* R1, int ldr1,
+    const float* R2, int ldr2, const float* __restrict__ V, int ldv, const float* __restrict__ fw, int M, int N, int K, int relu) {
+  __shared__ float red[kWaves][32 * (CW + 1)];
+  __shared__ float s_mean[kRows], s_rstd[kRows];
+  const int n0 = blockIdx.x * CW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  if (LN) row_stats(X, ldx, M, D, eps, s_mean, s_rstd);
+  const float mean = LN ? s_mean[r] : 0.f, rstd = LN ? s_rstd[r] : 0.f;
+  const int nkb = K >> 3;
+  const int per = (nkb + kWaves - 1) / kWaves;
+  const int kb0 = wave * per;
+  const int kb1 = kb0 + per < nkb ? kb0 + per : nkb;
+  const float* ap = X + (size_t)(r < M ? r : M - 1) * ldx + 4 * h;
+  const bool wlive = r < CW;
+  const float* wp = W + (size_t)(n0 + (wlive ? r : 0)) * ldw + 4 * h;      // weight rows up to the 128-row padding are readable
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto norm = [&](float4 a, int k) {
+    if (!LN) return a;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < D) {               // D % 4 == 0: a float4 is inside or outside as a whole
+      const float4 gg = *reinterpret_cast<const float4*>(g + k);
+      const float4 bb = *reinterpret_cast<const float4*>(b + k);
+      o.x = (a.x - mean) * rstd * gg.x + bb.x; o.y = (a.y - mean) * rstd * gg.y + bb.y;
+      o.z = (a.z - mean) * rstd * gg.z + bb.z; o.w = (a.w - mean) * rstd * gg.w + bb.w;
+    }
+    return o;
+  };
+  int kb = kb0;
+  for (; kb + 4 <= kb1; kb += 4) {
+    float4 a[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const float4*>(ap + 8 * (kb + u));
+      w[u] = wlive ? *reinterpret_cast<const float4*>(wp + 8 * (kb + u)) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 an = norm(a[u], 8 * (kb + u) + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.x, w[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.y, w[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.z, w[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.w, w[u].w, acc, 0, 0, 0);
+    }
+  }
+  for (; kb < kb1; ++kb) {
+    const float4 an = norm(*reinterpret_cast<const float4*>(ap + 8 * kb), 8 * kb + 4 * h);
+    const float4 w = wlive ? *reinterpret_cast<const float4*>(wp + 8 * kb) : zero4;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.z, w.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an.w, w.w, acc, 0, 0, 0);
+  }
+  // D[i = activation row][j = weight column]: col j = lane & 31, row i = (e & 3) + 8 * (e >> 2) + 4 * h
+  if (wlive) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * h) * (CW + 1) + r] = acc[e];
+  }
+  __syncthreads();
+  if (tid >= 32 * CW) return;
+  const int row = tid / CW, col = tid % CW;          // 32 x CW outputs
+  const int gcol = n0 + col;
+  if (row >= M || gcol >= N) return;
+  const int o = row * (CW + 1) + col;
+  float v = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < kWaves; ++w2) v += red[w2][o];
+  if (bias) v += bias[gcol];
+  if (R1) v += R1[(size_t)row * ldr1 + gcol];
+  if (R2) v += R2[(size_t)row * ldr2 + gcol];
+  if (V) {
+    float mem = V[(size_t)row * ldv + gcol];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int t = row + j - 5;
+      if (t >= 0 && t < M) mem += fw[gcol * 11 + j] * V[(size_t)t * ldv + gcol];
+    }
+    v += mem;
+  }
+  if (relu) v = fmaxf(v, 0.f);
+  C[(size_t)row * ldc + gcol] = v;
+}
+
+
+// ---- the same operator on the vector ALUs -----------------------------------------------------------------------------------
+// Measured on one window (profiles/r02/stream_one_by_kernel_a.txt): the MFMA form above spends 7 us (K = 512) to 23 us
+// (K = 2048) per launch whatever the patch width, because a 32 x 32 x K tile on `v_mfma_f32_32x32x2_f32` costs K/2 x 64 cycles
+// spread over 4 SIMDs — 7.8 us at K = 2048 — and only 20 x CW of its 1024 outputs are wanted.  The fp32 MFMA runs at the fp32
+// VECTOR rate, so nothing is lost by computing exactly the wanted M x CW outputs with v_fma: lane = (output column c, k-subset),
+// every lane keeps one accumulator per activation row, reads float4s of its weight row and of every activation row (the same
+// address in the CW lanes of a k-subset: one fetch), and the k-subsets are summed with log2(64 / CW) xor-shuffles, the waves
+// through LDS in wave order (deterministic).  Per workgroup: 20 x CW x K FMAs (a few hundred per thread), CW x K weights
+// from HBM, M x K activations from L2.  Measured in isolation on cold weights (tools/fused_gemv_bench.py): 6.7 us at
+// N = K = 512, 11 us for QKV / FFN1, 14-18 us at K = 2048 (the MFMA form: 7 / 10 / 20-26); the vocabulary projection
+// (N = 8404) stays on the MFMA form (20 vs 42 us).  Tried and dropped: staging the activation slab through LDS with every
+// independent load issued up front (one trip to memory instead of three): 9.6 us at N = K = 512 and 33-56 us with LayerNorm.
+template <bool LN, int CW, int MR>
+__global__ __launch_bounds__(1024) void fused_ln_gemv_kernel(
+    const float* __restrict__ X, int ldx, int D, const float* __restrict__ g, const float* __restrict__ b, float eps,
+    const float* __restrict__ W, int ldw, float* C, int ldc, const float* __restrict__ bias, const float* R1, int ldr1,
+    const float* R2, int ldr2, const float* __restrict__ V, int ldv, const float* __restrict__ fw, int M, int N, int K, int relu) {
+  constexpr int KS = 64 / CW;            // k-subsets per wave
+  constexpr int KI = 4 * KS;             // k per wave and iteration
+  __shared__ float red[kWaves][MR * CW];
+  __shared__ float s_mean[kRows], s_rstd[kRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const int c = lane % CW, ks = lane / CW;
+  const int n0 = blockIdx.x * CW;
+  const float* wrow = W + (size_t)(n0 + c) * ldw;           // weight rows up to the 128-row padding are readable
+  // the lane's first weight float4 does not depend on anything: in flight while the row statistics are computed
+  const int n_blocks = K / KI;
+  float4 w_first = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave < n_blocks) w_first = *reinterpret_cast<const float4*>(wrow + wave * KI + 4 * ks);
+  if (LN) {
+    // row statistics, two passes over values held in registers (one trip to memory): 32 threads per row, rows in rounds
+    for (int row = tid >> 5; row < kRows; row += blockDim.x >> 5) {
+      const int cc = tid & 31;
+      float mean = 0.f, rstd = 0.f;
+      if (row < M) {
+        const float* xr = X + (size_t)row * ldx;
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int k = 4 * cc + 128 * u;
+          v[u] = k < D ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        mean = sum / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (4 * cc + 128 * u < D) {
+            const float a0 = v[u].x - mean, a1 = v[u].y - mean, a2 = v[u].z - mean, a3 = v[u].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+          }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        rstd = 1.0f / sqrtf(q / (float)D + eps);
+      }
+      if (cc == 0) { s_mean[row] = mean; s_rstd[row] = rstd; }
+    }
+    __syncthreads();
+  }
+  float acc[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) acc[i] = 0.f;
+  for (int kbk = wave; kbk < n_blocks; kbk += n_waves) {
+    const int k = kbk * KI + 4 * ks;
+    const float4 w4 = kbk == wave ? w_first : *reinterpret_cast<const float4*>(wrow + k);
+    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f), bb = gg;
+    const bool live = !LN || k < D;
+    if (LN && live) { gg = *reinterpret_cast<const float4*>(g + k); bb = *reinterpret_cast<const float4*>(b + k); }
+    // rows in groups of 8: eight 16-byte loads in flight per lane (x 16 waves) cover the latency; more would spill at the
+    // 128 registers a 1024-thread workgroup leaves each lane
+#pragma unroll
+    for (int i0 = 0; i0 < MR; i0 += 8) {
+      float4 a[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const float4*>(X + (size_t)(i0 + i < M ? i0 + i : M - 1) * ldx + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 v = a[i];
+        if (LN) {
+          const float mu = s_mean[i0 + i], rs = s_rstd[i0 + i];
+          v.x = (v.x - mu) * rs * gg.x + bb.x; v.y = (v.y - mu) * rs * gg.y + bb.y;
+          v.z = (v.z - mu) * rs * gg.z + bb.z; v.w = (v.w - mu) * rs * gg.w + bb.w;
+          if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        acc[i0 + i] = fmaf(v.x, w4.x, acc[i0 + i]); acc[i0 + i] = fmaf(v.y, w4.y, acc[i0 + i]);
+        acc[i0 + i] = fmaf(v.z, w4.z, acc[i0 + i]); acc[i0 + i] = fmaf(v.w, w4.w, acc[i0 + i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // sum the k-subsets of the wave (lanes c, c + CW, ...), then the waves in order
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 32; o >= CW; o >>= 1) v += __shfl_xor(v, o);
+    acc[i] = v;
+  }
+  if (ks == 0) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i) red[wave][i * CW + c] = acc[i];
+  }
+  __syncthreads();
+  if (tid >= MR * CW) return;
+  const int row = tid / CW, col = tid % CW, gcol = n0 + col;
+  if (row >= M || gcol >= N) return;
+  float v = 0.f;
+  for (int w2 = 0; w2 < n_waves; ++w2) v += red[w2][tid];
+  if (bias) v += bias[gcol];
+  if (R1) v += R1[(size_t)row * ldr1 + gcol];
+  if (R2) v += R2[(size_t)row * ldr2 + gcol];
+  if (V) {
+    float mem = V[(size_t)row * ldv + gcol];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int t = row + j - 5;
+      if (t >= 0 && t < M) mem += fw[gcol * 11 + j] * V[(size_t)t * ldv + gcol];
+    }
+    v += mem;
+  }
+  if (relu) v = fmaxf(v, 0.f);
+  C[(size_t)row * ldc + gcol] = v;
+}
+
+}  // namespace
+
+template <bool LN, int CW>
+static void launch_gemv(const float* X, int ldx, int D, const float* g, const float* b, float eps, const float* W, int ldw, float* C,
+                        int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, const float* fsmn_v, int ldv,
+                        const float* fsmn_w, int M, int N, int K, bool relu, hipStream_t s) {
+  constexpr int KI = 4 * (64 / CW);
+  // LayerNorm needs 32 threads per row for its statistics: all 16 waves; without it, one wave per k-block is enough
+  const int waves = g ? kWaves : std::max(1, std::min(kWaves, K / KI));
+  const dim3 grid((N + CW - 1) / CW), block(64 * waves);
+#define PFHIP_LAUNCH(MR_)                                                                                                            \
+  hipLaunchKernelGGL((fused_ln_gemv_kernel<LN, CW, MR_>), grid, block, 0, s, X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, \
+                     ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu ? 1 : 0)
+  if (M <= 8) PFHIP_LAUNCH(8); else if (M <= 16) PFHIP_LAUNCH(16); else if (M <= 24) PFHIP_LAUNCH(24); else PFHIP_LAUNCH(32);
+#undef PFHIP_LAUNCH
+}
+
+void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const float* b, float eps, const float* W, int ldw,
+                          float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+                          const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, bool relu, hipStream_t s) {
+  if (M <= 0 || N <= 0) return;
+  // patch width: at least ~128 workgroups per launch (N = 512 -> 4 columns, 1024-2048 -> 8, the vocabulary -> 32)
+  const int cw = N <= 640 ? 4 : (N <= 4096 ? 8 : 32);
+  static const bool use_mfma = [] { const char* e = getenv("PFHIP_STREAM_FUSED_MFMA"); return e && e[0] == '1'; }();
+  if (!use_mfma && K % 64 == 0 && N <= 4096) {
+    if (g) {
+      if (cw == 4) launch_gemv<true, 4>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      else if (cw == 8) launch_gemv<true, 8>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      else launch_gemv<true, 32>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+    } else {
+      if (cw == 4) launch_gemv<false, 4>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      else if (cw == 8) launch_gemv<false, 8>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      else launch_gemv<false, 32>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+    }
+    return;
+  }
+  const dim3 grid((N + cw - 1) / cw), block(kThreads);
+#define PFHIP_LAUNCH(LN_, CW_)                                                                                                    \
+  hipLaunchKernelGGL((fused_ln_gemm_kernel<LN_, CW_>), grid, block, 0, s, X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, \
+                     ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu ? 1 : 0)
+  if (g) {
+    if (cw == 4) PFHIP_LAUNCH(true, 4); else if (cw == 8) PFHIP_LAUNCH(true, 8); else PFHIP_LAUNCH(true, 32);
+  } else {
+    if (cw == 4) PFHIP_LAUNCH(false, 4); else if (cw == 8) PFHIP_LAUNCH(false, 8); else PFHIP_LAUNCH(false, 32);
+  }
+#undef PFHIP_LAUNCH
+}
+
+}  // namespace pfhip

@@ -22,6 +22,8 @@ def _lib():
     if not _bound:
         lib.pfhip_op_gemm_f32.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_gemm_f32_kind.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
+        lib.pfhip_op_fused_ln_gemm.argtypes = [_vp, _ci, _ci, _vp, _vp, _cf, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp,
+                                               _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
         lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
@@ -65,6 +67,19 @@ def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guar
                                       _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
                                       R2.stride(0) if R2 is not None else 0, M, N, K, 1 if relu else 0,
                                       1 if guard else 0, kind, _stream()), "gemm")
+    return out
+
+
+def fused_ln_gemm(X, W, M, N, g=None, b=None, D=None, bias=None, R1=None, R2=None, fsmn_v=None, fsmn_w=None, relu=False, out=None,
+                  eps=1e-12):
+    """One streaming window: LN (if g) -> GEMM (+bias +R1 +R2 +FSMN memory of fsmn_v, ReLU) in one launch (M <= 32)."""
+    K = W.shape[1]
+    if out is None:
+        out = torch.zeros((32, round_up(N, 128)), dtype=torch.float32, device=X.device)
+    _ck(_lib().pfhip_op_fused_ln_gemm(_p(X), X.stride(0), K if D is None else D, _p(g), _p(b), eps, _p(W), W.stride(0), _p(out),
+                                      out.stride(0), _p(bias), _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
+                                      R2.stride(0) if R2 is not None else 0, _p(fsmn_v), fsmn_v.stride(0) if fsmn_v is not None else 0,
+                                      _p(fsmn_w), M, N, K, 1 if relu else 0, _stream()), "fused_ln_gemm")
     return out
 
 

@@ -41,6 +41,12 @@ int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* r
 /* LogSoftmax + ArgMax (GreedySearch/FindMax, onnxruntime/src/paraformer.cpp:386-395, util.cpp:63-74). */
 int pfhip_op_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids, void* stream);
 
+/* One streaming window (M <= 32 rows): LayerNormalization (g != NULL; width D <= K) -> MatMul/Gemm (+bias, +residual Adds, Relu)
+ * (+ the SAN-M FSMN memory of fsmn_v over the M rows, k = 11) in ONE launch — stream_fused.hip. */
+int pfhip_op_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const float* b, float eps, const float* W, int ldw,
+                           float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
+                           const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,14 @@
 // accumulation is fp32 in the matrix core as before.  Measured against an fp64 reference the result is slightly CLOSER than
 // the fp32 MFMA chain (rms 1.2e-7 vs 2.9e-7 relative at K = 512: the partial products carry no rounding of their own).
 //
+// Domain of the fp32-grade claim (pinned by tests/test_gpu_ops.py::test_gemm_bf16_split_stated_domain):
+//   * non-finite operands: x = +-Inf gives a2 = Inf - Inf = NaN, so every output of that activation row (or weight column)
+//     is NaN where an fp32 GEMM would carry +-Inf; a NaN operand gives NaN as it would there;
+//   * magnitudes below 2^-110: the third plane is 2^-16 of the operand and falls into bf16's denormal range, which the matrix
+//     cores flush: such operands keep ~16 significant bits.  Exact down to 2^-100.
+// Neither occurs behind a LayerNorm with finite weights; callers with unbounded inputs should use the fp32-MFMA kernels
+// (PFHIP_GEMM_X6=0).
+//
 // Tiling: 256 x 128 block tile, 8 waves as 4 x 2 (two per SIMD), each 64 x 64 = 2 x 2 MFMA tiles.  K-step 16 = one MFMA depth.
 // Operands are split while they are staged: global fp32 -> registers -> three bf16 planes in LDS (row stride 48 B: the 16-lane
 // groups of ds_read_b128 hit 16 distinct 16-B slots), double-buffered, one barrier per K-step; the split of the NEXT step's

@@ -250,16 +250,54 @@ def test_gemm_bf16_split_is_fp32_grade(ops):
     ref = A.astype(np.float64) @ W.astype(np.float64).T
     norm = np.sqrt((A.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
     err = {}
-    for kind in (1, 4, 5):
+    for kind in (1, 4, 5, 6):
         C = ops.gemm_f32(dA, dW, M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
         err[kind] = float((np.abs(C - ref) / norm).max())
-    assert err[4] <= 1.5 * err[1] + 1e-9 and err[5] <= 1.5 * err[1] + 1e-9, err
-    assert err[4] < 5e-7 and err[5] < 5e-7, err
+    assert err[4] <= 1.5 * err[1] + 1e-9 and err[5] <= 1.5 * err[1] + 1e-9 and err[6] <= 1.5 * err[1] + 1e-9, err
+    assert err[4] < 5e-7 and err[5] < 5e-7 and err[6] < 5e-7, err
     Ai = rng.integers(-700, 700, (300, 32)).astype(np.float32)                 # 10-bit operands (two planes); sums < 2^24: exact
     Wi = rng.integers(-700, 700, (256, 32)).astype(np.float32)
-    for kind in (4, 5):
+    for kind in (4, 5, 6):
         C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=kind).cpu().numpy()[:300, :256]
         assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))
+
+
+def test_gemm_bf16_split_stated_domain(ops):
+    """Where the three-plane split (gemm_x6.hip: rest(x) = x - top16(x)) stops being an fp32 GEMM, pinned:
+      * a non-finite operand: Inf - Inf = NaN in the second plane, so EVERY output of that row is NaN (an fp32 GEMM would carry
+        +-Inf through, NaN only where signs cancel); rows without non-finite operands are untouched;
+      * operands below 2^-110: the third plane (2^-16 of the operand) falls into bf16's denormal range and the matrix cores
+        flush it — the result keeps ~16 significant bits instead of 24.  Down to 2^-100 the split is exact.
+    Neither is reachable from LayerNorm-ed activations and finite weights; this test states the domain of the precision claim."""
+    rng = np.random.default_rng(6)
+    M, N, K = 256, 256, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    A[3, 17] = np.inf
+    A[9, 100] = -np.inf
+    A[40, 5] = np.nan
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    for kind in (4, 5, 6):
+        C = ops.gemm_f32(dev(pad_rows(A)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
+        for r in (3, 9, 40):
+            assert np.isnan(C[r]).all(), (kind, r)                    # the fp32-MFMA kernel gives +-Inf in rows 3 and 9
+        ok = [r for r in range(M) if r not in (3, 9, 40)]
+        assert np.isfinite(C[ok]).all() and np.abs(C[ok] - ref[ok]).max() < 3e-5, kind
+    Cf = ops.gemm_f32(dev(pad_rows(A)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=1).cpu().numpy()[:M, :N]
+    assert np.isinf(Cf[3]).all() and np.isinf(Cf[9]).all() and np.isnan(Cf[40]).all()
+    # magnitude floor: rows scaled by 2^-100 are still fp32-grade, rows at 2^-118 keep at least 14 bits
+    A2 = rng.standard_normal((M, K)).astype(np.float32)
+    scale = np.ones((M, 1), np.float32)
+    scale[:128] = np.float32(2.0 ** -100)
+    scale[128:] = np.float32(2.0 ** -118)
+    A2 = (A2 * scale).astype(np.float32)
+    ref2 = A2.astype(np.float64) @ W.astype(np.float64).T
+    norm = np.sqrt((A2.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
+    for kind in (4, 5, 6):
+        C = ops.gemm_f32(dev(pad_rows(A2)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
+        rel = np.abs(C - ref2) / norm
+        assert rel[:128].max() < 5e-7, (kind, rel[:128].max())
+        assert rel[128:].max() < 2.0 ** -14, (kind, rel[128:].max())
 
 
 def test_fp32_mfma_kernels_behind_the_opt_out_knobs():
@@ -275,3 +313,41 @@ def test_fp32_mfma_kernels_behind_the_opt_out_knobs():
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+@pytest.mark.parametrize("M,N,K,D,ln,fsmn", [(20, 1536, 512, 512, True, False), (20, 1536, 576, 560, True, False), (20, 512, 512, 512, False, True),
+                                              (1, 512, 2048, 2048, True, False), (7, 2048, 512, 512, True, False), (32, 512, 2048, 2048, False, False),
+                                              (13, 8404, 512, 512, True, False), (20, 16384, 512, 512, False, False), (9, 1003, 512, 512, True, False)])
+def test_fused_ln_gemm_one_window(ops, M, N, K, D, ln, fsmn):
+    """stream_fused.hip: LayerNorm (non-trivial gamma / beta, width D <= K) -> GEMM (+bias, +residual, ReLU) (+ the SAN-M FSMN
+    memory of a value matrix over the M rows) in ONE launch, against fp64; both forms (vector-ALU GEMV for N <= 4096, MFMA for the
+    vocabulary-sized ones)."""
+    rng = np.random.default_rng(M * 1000 + N)
+    Np = (N + 127) // 128 * 128
+    X = np.zeros((32, K), np.float32)
+    X[:M, :D] = (rng.standard_normal((M, D)) * 3 + 1.5).astype(np.float32)
+    W = np.zeros((Np + 128, K), np.float32)
+    W[:N, :D] = (rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32)
+    g = (rng.random(K) + 0.5).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.2).astype(np.float32)
+    bias = np.zeros(Np, np.float32); bias[:N] = rng.standard_normal(N)
+    R = rng.standard_normal((32, Np)).astype(np.float32)
+    V = rng.standard_normal((32, Np)).astype(np.float32)
+    fw = (rng.standard_normal((Np, 11)) / 3).astype(np.float32)
+    xd = X[:M, :D].astype(np.float64)
+    if ln:
+        xd = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-12) * g[:D] + b[:D]
+    ref = xd @ W[:N, :D].astype(np.float64).T + bias[:N] + R[:M, :N]
+    if fsmn:
+        mem = V[:M, :N].astype(np.float64).copy()
+        for t in range(M):
+            for j in range(11):
+                s = t + j - 5
+                if 0 <= s < M:
+                    mem[t] += fw[:N, j] * V[s, :N]
+        ref = ref + mem
+    ref = np.maximum(ref, 0)
+    out = ops.fused_ln_gemm(dev(X), dev(W), M, N, g=dev(g) if ln else None, b=dev(b) if ln else None, D=D, bias=dev(bias), R1=dev(R),
+                            fsmn_v=dev(V) if fsmn else None, fsmn_w=dev(fw) if fsmn else None, relu=True).cpu().numpy()
+    assert np.abs(out[:M, :N] - ref).max() < 5e-5 * np.sqrt(K / 512)
+    assert not out[M:].any()                 # rows beyond M are not written

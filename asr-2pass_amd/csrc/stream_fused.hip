@@ -180,7 +180,9 @@ __global__ __launch_bounds__(kThreads) void fused_ln_gemm_kernel(
 // from HBM, M x K activations from L2.  Measured in isolation on cold weights (tools/fused_gemv_bench.py): 6.7 us at
 // N = K = 512, 11 us for QKV / FFN1, 14-18 us at K = 2048 (the MFMA form: 7 / 10 / 20-26); the vocabulary projection
 // (N = 8404) stays on the MFMA form (20 vs 42 us).  Tried and dropped: staging the activation slab through LDS with every
-// independent load issued up front (one trip to memory instead of three): 9.6 us at N = K = 512 and 33-56 us with LayerNorm.
+// independent load issued up front (one trip to memory instead of three): 9.6 us at N = K = 512 and 33-56 us with LayerNorm;
+// prefetching the first row group's raw values across the statistics barrier (30-50 spilled registers at the 128 a 1024-thread
+// workgroup leaves: 23-27 us).
 template <bool LN, int CW, int MR>
 __global__ __launch_bounds__(1024) void fused_ln_gemv_kernel(
     const float* __restrict__ X, int ldx, int D, const float* __restrict__ g, const float* __restrict__ b, float eps,
@@ -320,28 +322,33 @@ void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const 
                           const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, bool relu, hipStream_t s) {
   if (M <= 0 || N <= 0) return;
   // patch width: at least ~128 workgroups per launch (N = 512 -> 4 columns, 1024-2048 -> 8, the vocabulary -> 32)
-  const int cw = N <= 640 ? 4 : (N <= 4096 ? 8 : 32);
+  // (N = 512 at K = 2048: 2 columns -> 256 workgroups and ONE k-block per wave instead of two: three dependent round trips to L2
+  // per lane instead of six)
+  const int cw = N <= 640 ? (K >= 1024 ? 2 : 4) : (N <= 4096 ? 8 : 32);
   static const bool use_mfma = [] { const char* e = getenv("PFHIP_STREAM_FUSED_MFMA"); return e && e[0] == '1'; }();
   if (!use_mfma && K % 64 == 0 && N <= 4096) {
     if (g) {
-      if (cw == 4) launch_gemv<true, 4>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      if (cw == 2) launch_gemv<true, 2>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      else if (cw == 4) launch_gemv<true, 4>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
       else if (cw == 8) launch_gemv<true, 8>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
       else launch_gemv<true, 32>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
     } else {
-      if (cw == 4) launch_gemv<false, 4>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      if (cw == 2) launch_gemv<false, 2>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
+      else if (cw == 4) launch_gemv<false, 4>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
       else if (cw == 8) launch_gemv<false, 8>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
       else launch_gemv<false, 32>(X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu, s);
     }
     return;
   }
-  const dim3 grid((N + cw - 1) / cw), block(kThreads);
+  const int cwm = cw == 2 ? 4 : cw;
+  const dim3 grid((N + cwm - 1) / cwm), block(kThreads);
 #define PFHIP_LAUNCH(LN_, CW_)                                                                                                    \
   hipLaunchKernelGGL((fused_ln_gemm_kernel<LN_, CW_>), grid, block, 0, s, X, ldx, D, g, b, eps, W, ldw, C, ldc, bias, R1, ldr1, R2, \
                      ldr2, fsmn_v, ldv, fsmn_w, M, N, K, relu ? 1 : 0)
   if (g) {
-    if (cw == 4) PFHIP_LAUNCH(true, 4); else if (cw == 8) PFHIP_LAUNCH(true, 8); else PFHIP_LAUNCH(true, 32);
+    if (cwm == 4) PFHIP_LAUNCH(true, 4); else if (cwm == 8) PFHIP_LAUNCH(true, 8); else PFHIP_LAUNCH(true, 32);
   } else {
-    if (cw == 4) PFHIP_LAUNCH(false, 4); else if (cw == 8) PFHIP_LAUNCH(false, 8); else PFHIP_LAUNCH(false, 32);
+    if (cwm == 4) PFHIP_LAUNCH(false, 4); else if (cwm == 8) PFHIP_LAUNCH(false, 8); else PFHIP_LAUNCH(false, 32);
   }
 #undef PFHIP_LAUNCH
 }

@@ -290,6 +290,24 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
                        kv_len, q_kv_limit, scale);
 }
 
+static bool att_x6_on() {
+  static const bool x6 = [] { const char* e = getenv("PFHIP_ATT_X6"); return !(e && e[0] == '0'); }();
+  return x6;
+}
+
+void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                           const int* off, const int* len, int B, int H, int max_len, float scale, const float* fsmn_w, float* mem,
+                           int ldmem, hipStream_t s) {
+  if (B <= 0 || max_len <= 0) return;
+  static const bool fuse = [] { const char* e = getenv("PFHIP_ATT_FSMN"); return !(e && e[0] == '0'); }();
+  if (fuse && att_x6_on() && max_len > 64) {
+    launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem);
+    return;
+  }
+  launch_fsmn(V, ldv, fsmn_w, nullptr, 0, mem, ldmem, off, len, B, max_len, H * kHeadDim, s);
+  launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s);
+}
+
 void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                          int max_q_len, float scale, int head_dim, hipStream_t s) {

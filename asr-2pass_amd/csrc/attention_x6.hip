@@ -53,7 +53,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& 
 __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
     const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
     float* __restrict__ O, int ldo, const int* __restrict__ q_off, const int* __restrict__ q_len,
-    const int* __restrict__ kv_off, const int* __restrict__ kv_len, float scale) {
+    const int* __restrict__ kv_off, const int* __restrict__ kv_len, float scale, const float* __restrict__ fsmn_w,
+    float* __restrict__ mem, int ldmem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int b = blockIdx.y, head = blockIdx.x;
@@ -64,6 +65,47 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
   const size_t qbase = (size_t)q_off[b], kbase = (size_t)kv_off[b];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+
+  // ---- SAN-M memory block of the encoder layer, for this workgroup's 256 rows x this head's 128 channels (self-attention
+  // only: q rows = kv rows): mem[t][c] = v[t][c] + sum_j w[c][j] v[t + j - 5][c], zero outside the utterance — the fsmn_kernel of
+  // rowops.hip (same operation order: bit-identical), folded in here because the (head, utterance, query block) grid covers
+  // every (row, channel) exactly once and the V rows are about to be streamed anyway.  One launch and one 16.9-us kernel per
+  // encoder layer less; costs this workgroup ~2 us of its ~86.
+  if (fsmn_w) {
+    constexpr int kTaps = 11, kStrip = 16;
+    const int cg = tid & 31, strip = tid >> 5;
+    const int c = head * kHD + 4 * cg, t0 = q0 + strip * kStrip;
+    if (t0 < Lk) {
+      float wk[4][kTaps];
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int j = 0; j < kTaps; ++j) wk[ch][j] = fsmn_w[(size_t)(c + ch) * kTaps + j];
+      float4 rows[kStrip + kTaps - 1];
+#pragma unroll
+      for (int j = 0; j < kStrip + kTaps - 1; ++j) {
+        const int t = t0 - 5 + j;
+        rows[j] = (t < 0 || t >= Lk) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(V + (kbase + t) * ldv + c);
+      }
+#pragma unroll
+      for (int s = 0; s < kStrip; ++s) {
+        const int t = t0 + s;
+        if (t < Lk) {
+          float4 o = rows[s + 5];
+          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int j = 0; j < kTaps; ++j) {
+            a.x += wk[0][j] * rows[s + j].x;
+            a.y += wk[1][j] * rows[s + j].y;
+            a.z += wk[2][j] * rows[s + j].z;
+            a.w += wk[3][j] * rows[s + j].w;
+          }
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+          *reinterpret_cast<float4*>(mem + (kbase + t) * ldmem + c) = o;
+        }
+      }
+    }
+  }
 
   // ---- Q planes of this lane: query row q0 + wave*32 + r, k-step s covers d = 16s + 8h + (0..7) ----------------------------
   bf16x8 qf[8][3];
@@ -332,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
 
 void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
-                         float scale, hipStream_t s) {
+                         float scale, hipStream_t s, const float* fsmn_w, float* mem, int ldmem) {
   if (B <= 0 || max_q_len <= 0) return;
   static std::atomic<unsigned long long> attr_done{0};      // > 64 KB of dynamic LDS needs the opt-in once per device
   int dev = 0;
@@ -344,7 +386,7 @@ void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const
   }
   const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(512);
   hipLaunchKernelGGL(attention_x6_kernel, grid, block, kLdsBytes, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
-                     kv_len, scale);
+                     kv_len, scale, fsmn_w, mem, ldmem);
 }
 
 }  // namespace pfhip

@@ -88,9 +88,16 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
 // With a per-query key limit: query row i (packed index) only sees keys [0, min(kv_len, q_kv_limit[i])) — the
 // prefix mask CTTransformerOnline::VadMask builds (ct-transformer-online.cpp:225-240).
 // both attention products on the BF16 matrix cores (exact three-way split, attention_x6.hip); d_k = 128, no per-query limits
+// fsmn_w != nullptr (self-attention only: q segments == kv segments): the kernel also writes the encoder layer's FSMN memory
+// mem = V + depthwise conv k = 11 over time (what launch_fsmn computes, bit for bit) for its rows and its head's channels
 void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
-                         float scale, hipStream_t s);
+                         float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0);
+// Encoder-layer pair: FSMN memory of V (into mem) + self-attention (into O).  One launch where the BF16 attention kernel runs
+// (d_k = 128, more than 64 queries per utterance), otherwise launch_fsmn + launch_attention.  C = V's channel count (H * 128).
+void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                           const int* off, const int* len, int B, int H, int max_len, float scale, const float* fsmn_w, float* mem,
+                           int ldmem, hipStream_t s);
 void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                              const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
                              const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s);

@@ -420,14 +420,10 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     gemm(m, s, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
          m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
     {
-      Scope sc(m, s, K_FSMN, 2.0 * 11 * M * d, 8.0 * M * d);
-      pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, m->m_row_off,
-                         m->m_len, B, m->maxT, d, s);
-    }
-    {
-      Scope sc(m, s, K_ATTN, 4.0 * attn_pairs * d, 16.0 * M * d);
-      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d,
-                              m->m_row_off, m->m_len, m->m_row_off, m->m_len, B, c.n_head, m->maxT, att_scale, s);
+      // FSMN memory of V + self-attention: one launch where the BF16 attention kernel runs (attention_x6.hip), else two
+      Scope sc(m, s, K_ATTN, 4.0 * attn_pairs * d + 2.0 * 11 * M * d, 24.0 * M * d);
+      pfhip::launch_attention_fsmn(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, m->m_row_off,
+                                   m->m_len, B, c.n_head, m->maxT, att_scale, m->W(p + "fsmn.w").d, m->mem.f(), d, s);
     }
     // x = (first ? 0 : x) + ctx*Wo + b + fsmn_memory
     gemm(m, s, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,

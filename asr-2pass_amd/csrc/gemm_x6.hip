@@ -66,10 +66,33 @@ __device__ __forceinline__ void tile_of_block_x6(int bid, int n_tiles, int tiles
   }
 }
 
+// LayerNorm statistics of the rows this tile just finished, for the GEMM that consumes them (LN-on-load below): the 32 lanes
+// that hold one row's 128 columns reduce (mean of the tile's columns, M2 = sum of squared deviations from THAT mean) and lane 0
+// writes the pair to stats[row][tile column][2].  The consumer merges the tiles_n pairs of a row with Chan's formula — as
+// accurate as a two-pass LayerNorm, no atomics, no ordering between tiles.
+// sum over the 32 lanes of a half wave, result in every lane: four DPP steps inside the 16-lane rows (quad swaps, half-row
+// mirror, row mirror — vector-ALU speed) and ONE cross-row shuffle; five ds_bpermute round trips per sum cost the epilogue
+// ~2 us per tile
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  v += __shfl_xor(v, 16);
+  return v;
+}
+__device__ __forceinline__ void tile_row_stats(const float4& v, int grow, int M, int tn, int tiles_n, int c4, float* __restrict__ stats) {
+  const float sum = half_wave_sum((v.x + v.y) + (v.z + v.w));
+  const float mean = sum * (1.0f / kBN);
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+  const float q = half_wave_sum((a * a + b * b) + (c * c + d * d));
+  if (c4 == 0 && grow < M) *reinterpret_cast<float2*>(stats + ((size_t)grow * tiles_n + tn) * 2) = make_float2(mean, q);
+}
+
 __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
-    int n_tiles, int gw, int relu) {
+    int n_tiles, int gw, int relu, float* __restrict__ stats_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -234,6 +257,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
           C[(size_t)grow * ldc + gcol + q] = o;
         }
       }
+      if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
     }
     __syncthreads();
   }
@@ -249,10 +273,11 @@ constexpr int kSStageB = 6 * kSPlane;                       // 36,864 B
 constexpr int kSLdsBytes = 2 * kSStageB;                    // 73,728 B
 static_assert(kSM * kCs * 4 <= kSLdsBytes, "C tile must fit the operand buffers");
 
+template <bool LN>
 __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
-    int n_tiles, int gw, int relu) {
+    int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -270,6 +295,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
   const int a_fr = (wr * 64 + r) * kRowB + 16 * h;
   const int w_fr = 3 * kSPlane + (wc * 32 + r) * kRowB + 16 * h;
 
+  // LayerNorm on load (ln_stats != nullptr): the A operand is the raw residual stream; this thread's row is normalised as
+  // (x - mean) * rstd while it is staged — gamma is folded into the weights and beta into the bias by the caller.  mean / rstd
+  // come from the per-tile pairs the producing GEMM left (tile_row_stats), merged with Chan's formula (ln_tiles tiles of 128).
+  float ln_mean = 0.f, ln_rstd = 1.f;
+  if (LN) {
+    const float* sp = ln_stats + (size_t)min(m0 + srow, M - 1) * ln_tiles * 2;
+    float msum = 0.f, m2 = 0.f;
+    for (int t = 0; t < ln_tiles; ++t) msum += sp[2 * t];
+    ln_mean = msum / (float)ln_tiles;
+    for (int t = 0; t < ln_tiles; ++t) { const float dm = sp[2 * t] - ln_mean; m2 += sp[2 * t + 1] + (float)kBN * dm * dm; }
+    ln_rstd = 1.0f / sqrtf(m2 / (float)(ln_tiles * kBN) + ln_eps);
+  }
+
   float4 xa, xw, ya, yw;
 #define PFHIP_LOAD_RAW(RA, RW, k0)                            \
   RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
@@ -285,8 +323,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
     p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
     *reinterpret_cast<uint2*>(base + 2 * kSPlane) = p;
   };
+  auto ln_apply = [&](const float4& v) {
+    return make_float4((v.x - ln_mean) * ln_rstd, (v.y - ln_mean) * ln_rstd, (v.z - ln_mean) * ln_rstd, (v.w - ln_mean) * ln_rstd);
+  };
 #define PFHIP_SPLIT_STORE(RA, RW, stage)                      \
-  split3(RA, lds + (stage) * kSStageB + a_st);                \
+  split3(LN ? ln_apply(RA) : RA, lds + (stage) * kSStageB + a_st); \
   split3(RW, lds + (stage) * kSStageB + w_st);
 
   f32x16 acc0, acc1;
@@ -392,14 +433,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
         C[(size_t)grow * ldc + gcol + q] = o;
       }
     }
+    if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
   }
 }
 
 }  // namespace
 
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
-                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile) {
+                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
+                            const float* ln_stats, int ln_tiles, float* stats_out) {
   if (M <= 0 || N <= 0) return;
+  if (ln_stats) small_tile = true;              // LayerNorm-on-load lives in the 128 x 128 kernel (its consumers have K = 512)
   // > 64 KB of dynamic LDS needs the opt-in once per device
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -407,21 +451,27 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
   if (!(attr_done.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kSLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kSLdsBytes);
     attr_done.fetch_or(1ull << (dev & 63));
   }
   if (small_tile) {
     const int tiles_m = (M + kSM - 1) / kSM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;
     gw = std::max(1, std::min(gw, tiles_n));
-    hipLaunchKernelGGL(gemm_f32_bf16x6_128_kernel, dim3(n_tiles), dim3(512), kSLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2,
-                       ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0);
+    if (ln_stats)
+      hipLaunchKernelGGL(gemm_f32_bf16x6_128_kernel<true>, dim3(n_tiles), dim3(512), kSLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+    else
+      hipLaunchKernelGGL(gemm_f32_bf16x6_128_kernel<false>, dim3(n_tiles), dim3(512), kSLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
     return;
   }
   const int tiles_m = (M + kBM - 1) / kBM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;
   gw = std::max(1, std::min(gw, tiles_n));
   hipLaunchKernelGGL(gemm_f32_bf16x6_kernel, dim3(n_tiles), dim3(512), kLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2,
-                     ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0);
+                     ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, stats_out);
 }
 
 }  // namespace pfhip

@@ -122,6 +122,9 @@ struct pfhip_model {
   float* d_vocab_bias = nullptr;  // dec.out.b padded to vocab_pad
   float* d_kv_all_w = nullptr;    // the decoder layers' kv.w stacked [layers * 2d][d] (+ bias): one launch projects a streaming window for all layers
   float* d_kv_all_b = nullptr;
+  // LayerNorm folded into its consumer GEMM (gemm_x6.hip LN-on-load): per encoder layer W * gamma (per input column) and
+  // bias + W beta, for qkv (layers >= 1) and ffn1; [layers][N][d] / [layers][N]
+  float* d_lnw_qkv = nullptr; float* d_lnb_qkv = nullptr; float* d_lnw_ffn1 = nullptr; float* d_lnb_ffn1 = nullptr;
   // timestamp head repacks: ConvTranspose1d as [3d][d] + tiled bias, both LSTM directions' input weights [8d][d] + summed
   // biases, recurrent weights [2][4d][d]
   float* d_up_w = nullptr; float* d_up_b = nullptr; float* d_wih = nullptr; float* d_bih = nullptr; float* d_whh = nullptr;
@@ -133,6 +136,7 @@ struct pfhip_model {
   Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
   Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw, hwkv;
   Buf sseg;                     // StreamSeg descriptors of a streaming batch
+  Buf lnstats;                  // per-row LayerNorm statistics handed from a producing GEMM's epilogue to the consumer [M][4][2]
   Buf kvall;                    // one window's K/V projections of every decoder layer [32][layers * 2d]
   Buf fbk, d_ops;               // streaming batch: fbank frames of all connections, operation descriptors
   void* h_ops = nullptr; size_t h_ops_cap = 0;       // pinned staging of the same (+ the batch's PCM)

@@ -189,3 +189,34 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
         assert err < 1e-3, err
         assert err < 1e-4, err            # what fp32 end to end actually gives
     model.close()
+
+
+def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod):
+    """Batches of >= 4096 rows take the fused encoder path (pfhip.cpp `fuse_ln`): the GEMMs that write the residual stream leave
+    per-tile row statistics, the GEMMs that read it normalise on load with gamma folded into their weights and beta into their
+    bias.  Here gamma in [0.5, 1.5] and beta in [-0.5, 0.5] for every LayerNorm (the default synthetic weights keep them within
+    5 % of 1 / 0), 9 x 30 s = 4500 rows, against the oracle's explicit two-pass LayerNorm."""
+    cfg = weights_mod.small_config(enc_layers=4, dec_layers=1, vocab=700)
+    man, blob = weights_mod.synth_weights(cfg, seed=77)
+    rng = np.random.default_rng(5)
+    for name, t in man["tensors"].items():
+        if "norm" in name and (name.endswith(".g") or name.endswith(".b")):
+            o, n = t["offset"] // 4, int(np.prod(t["shape"]))
+            blob[o:o + n] = (rng.uniform(0.5, 1.5, n) if name.endswith(".g") else rng.uniform(-0.5, 0.5, n)).astype(np.float32)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    W = P.Weights(man, blob)
+    utts = [synth_pcm(i, 480000 - 1234 * i, rng) for i in range(9)]
+    got = model.forward_ids(utts, want_logp=True)
+    assert int(sum(got["n_frames"])) >= 4096
+    enc = model.get_tensor("enc", int(sum(got["n_frames"])) * 512).reshape(-1, 512)
+    o = 0
+    for i, u in enumerate(utts):
+        T = int(got["n_frames"][i])
+        if i in (0, 4, 8):
+            ref = P.forward_pcm(u, W)
+            assert np.abs(enc[o:o + T] - ref["enc"]).max() < 2e-4, i
+            assert int(got["token_num"][i]) == ref["token_num"]
+            assert list(got["ids"][i]) == list(ref["ids"])
+            assert np.abs(got["logp"][i] - ref["logp"]).max() < 1e-3
+        o += T
+    model.close()

@@ -111,6 +111,10 @@ struct StreamReq;
 struct pfhip_model {
   int device = 0;
   hipStream_t own_stream = nullptr;
+  // decoder K/V projections of a large batch run beside the (under-filled) token-side launches: pfhip.cpp enqueue_locked
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_enc_ready = nullptr;
+  std::vector<hipEvent_t> ev_kv;
   std::mutex mu;
   Config cfg;
   int feat_dim = 560, feat_pad = 576, vocab_pad = 8448;
@@ -136,6 +140,7 @@ struct pfhip_model {
   Buf pcm, meta, feats, x0, x, y, qkv, mem, ctx, hbuf, enc, alphas, counts;
   Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw, hwkv;
   Buf sseg;                     // StreamSeg descriptors of a streaming batch
+  Buf kvside;                   // [dec_layers][Mp][2d]: every decoder layer's K/V projection of the encoder output (side stream)
   Buf lnstats;                  // per-row LayerNorm statistics handed from a producing GEMM's epilogue to the consumer [M][4][2]
   Buf kvall;                    // one window's K/V projections of every decoder layer [32][layers * 2d]
   Buf fbk, d_ops;               // streaming batch: fbank frames of all connections, operation descriptors

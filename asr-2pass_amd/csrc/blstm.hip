@@ -179,6 +179,102 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
   }
 }
 
+// ---- fallback: one launch per time step ---------------------------------------------------------------------------------------
+// The persistent kernel needs the 32 blocks of a direction co-resident on one XCD; with another model's kernels on the device
+// (the 2-pass server runs VAD, punctuation and the streaming model beside this one) that is not guaranteed, and its bounded
+// spin then ends in an error flag.  This form has no inter-block exchange inside a launch: step t is one launch of 2 x 32
+// blocks, h travels through HBM/L2 between launches (kernel boundaries order it), the cell state lives in `cst`.  Same thread
+// mapping and MFMA sequence as above (bit-identical results); W_hh is re-read every step (8 MB from L2 / Infinity Cache).
+// ~3 us of launch boundary + ~6 us of work per step: about as fast as the persistent form's 9 us, but 1500 launches per 30-s batch.
+__global__ __launch_bounds__(kBlstmThreads, 1) void blstm_step_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                            float* __restrict__ y, float* hx, float* cst,
+                                                            const int* __restrict__ off, const int* __restrict__ len, int B, int t) {
+  __shared__ float red[kWaves][kMaxB][4 * kUnits];
+  const int dir = blockIdx.x & 1, blk = blockIdx.x >> 1;
+  const int unit0 = blk * kUnits;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int kbase = 4 * kKL * wave + kKL * kq;
+  float wreg[4][kKL];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* wrow = whh + ((size_t)dir * 4 * kH + (size_t)g * kH + unit0 + n) * kH + kbase;
+#pragma unroll
+    for (int s4 = 0; s4 < kKL / 4; ++s4) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * s4);
+      wreg[g][4 * s4] = v.x; wreg[g][4 * s4 + 1] = v.y; wreg[g][4 * s4 + 2] = v.z; wreg[g][4 * s4 + 3] = v.w;
+    }
+  }
+  const int cb = tid >> 4, cu = tid & 15;
+  const bool own = cb < B;
+  const int my_off = own ? off[cb] : 0, my_len = own ? len[cb] : 0;
+  const bool live = t < my_len;
+  const int frame = live ? my_off + (dir == 0 ? t : my_len - 1 - t) : 0;
+  float gpre[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* gp = gx + (size_t)frame * (8 * kH) + (size_t)dir * 4 * kH + unit0 + cu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gpre[g] = live ? gp[g * kH] : 0.f;
+  }
+  float* const hdir = hx + (size_t)dir * 2 * kMaxB * kH;
+  const float* hprev = hdir + (size_t)(t & 1) * kMaxB * kH;
+  float* hnext = hdir + (size_t)((t & 1) ^ 1) * kMaxB * kH;
+  const bool two_tiles = B > 16;
+  f32x4 ha[kKL / 4], hb[kKL / 4];
+  {
+    const float* a0 = hprev + (size_t)n * kH + kbase;
+#pragma unroll
+    for (int s4 = 0; s4 < kKL / 4; ++s4) {
+      ha[s4] = *reinterpret_cast<const f32x4*>(a0 + 4 * s4);
+      hb[s4] = two_tiles ? *reinterpret_cast<const f32x4*>(a0 + 16 * kH + 4 * s4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int s4 = 0; s4 < kKL / 4; ++s4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s4][e], wreg[g][4 * s4 + e], acc[0][g], 0, 0, 0);
+      if (two_tiles) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[s4][e], wreg[g][4 * s4 + e], acc[1][g], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][4 * kq + r][((g ^ kq) * kUnits) + n] = acc[0][g][r];
+      red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r];
+    }
+  __syncthreads();
+  if (own) {
+    float* cp = cst + ((size_t)dir * kMaxB + cb) * kH + unit0 + cu;
+    float c_state = t == 0 ? 0.f : *cp;
+    float h_state = t == 0 ? 0.f : hprev[(size_t)cb * kH + unit0 + cu];
+    if (live) {
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = (g ^ ((cb >> 2) & 3)) * kUnits + cu;
+        float a = gpre[g];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) a += red[w][cb][col];
+        pre[g] = a;
+      }
+      c_state = sigmoidf_(pre[1]) * c_state + sigmoidf_(pre[0]) * tanhf(pre[2]);
+      h_state = sigmoidf_(pre[3]) * tanhf(c_state);
+      y[(size_t)frame * (2 * kH) + (size_t)dir * kH + unit0 + cu] = h_state;
+    }
+    *cp = c_state;
+    hnext[(size_t)cb * kH + unit0 + cu] = h_state;
+  }
+}
+
 // a2[row] = relu(sigmoid(y[row] . w + b) * smooth - noise); one wave per row
 __global__ __launch_bounds__(256) void alpha2_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ w, float b,
                                                      float smooth, float noise, float* __restrict__ a2, int rows, int D) {
@@ -242,6 +338,17 @@ hipError_t launch_blstm(const float* gx, const float* whh, float* y, float* hx, 
   if (e != hipSuccess) return e;
   // one block per (XCD, slot): blocks 8 i + d land on XCD d; only d = 0, 1 work, the rest return at once
   hipLaunchKernelGGL(blstm_kernel, dim3(kXcds * kBlocksPerDir), dim3(kBlstmThreads), 0, s, gx, whh, y, hx, bar, off, len, B, Lmax);
+  return hipGetLastError();
+}
+
+hipError_t launch_blstm_stepwise(const float* gx, const float* whh, float* y, float* hx, float* cst, const int* off, const int* len, int B,
+                                 int Lmax, hipStream_t s) {
+  if (B <= 0 || Lmax <= 0) return hipSuccess;
+  if (B > kMaxB) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(hx, 0, (size_t)2 * 2 * kMaxB * kH * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  for (int t = 0; t < Lmax; ++t)
+    hipLaunchKernelGGL(blstm_step_kernel, dim3(2 * kBlocksPerDir), dim3(kBlstmThreads), 0, s, gx, whh, y, hx, cst, off, len, B, t);
   return hipGetLastError();
 }
 

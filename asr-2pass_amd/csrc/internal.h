@@ -145,9 +145,10 @@ struct pfhip_model {
   Buf kvall;                    // one window's K/V projections of every decoder layer [32][layers * 2d]
   Buf fbk, d_ops;               // streaming batch: fbank frames of all connections, operation descriptors
   void* h_ops = nullptr; size_t h_ops_cap = 0;       // pinned staging of the same (+ the batch's PCM)
-  Buf ts_up, ts_gx, ts_y, ts_hx, ts_a2, ts_alphas, ts_peaks, ts_meta;
+  Buf ts_up, ts_gx, ts_y, ts_hx, ts_a2, ts_alphas, ts_peaks, ts_meta, ts_cst;
   bool have_ts = false;
   int debug_blstm_flag = 0;        // pfhip_debug_poke
+  int blstm_fallbacks = 0;         // timestamp requests served by the per-step recurrence after a barrier time-out
   float out2_b = 0.f;
   int n_hw = 0;                  // hotword embeddings resident in `hw` ([n_hw, d])
   void* h_meta = nullptr; size_t h_meta_cap = 0;     // pinned

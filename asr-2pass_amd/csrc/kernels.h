@@ -124,6 +124,10 @@ constexpr int kBlstmScratchFloats = 2 * 2 * 32 * 512 + 8;
 constexpr int kBlstmFlagWord = 2 * 2 * 32 * 512 + 2;
 hipError_t launch_blstm(const float* gx, const float* whh, float* y, float* hx, const int* off, const int* len, int B, int Lmax,
                         hipStream_t s);
+// The same recurrence as one launch per time step (no inter-block exchange inside a launch: works whatever else runs on the
+// device); cst = 2 * 32 * 512 floats of cell state.  Same results bit for bit.
+hipError_t launch_blstm_stepwise(const float* gx, const float* whh, float* y, float* hx, float* cst, const int* off, const int* len, int B,
+                                 int Lmax, hipStream_t s);
 void launch_alpha2(const float* y, int ldy, const float* w, float b, float smooth, float noise, float* a2, int rows, int D,
                    hipStream_t s);
 void launch_us_cif(const float* a2, const int* off, const int* len, const int* token_num, int B, int max_len, float threshold,

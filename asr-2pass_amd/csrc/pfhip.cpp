@@ -693,11 +693,41 @@ pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
   gemm(m, s, m->ts_up.f(), d, m->d_wih, 8 * d, d, d, m->ts_gx.f(), 8 * d, m->d_bih, nullptr, 0, nullptr, 0, R, false);
   {
     Scope sc(m, s, K_OTHER, 2.0 * R * 8 * d * d, 4.0 * R * 10 * d);
-    for (int b0 = 0; b0 < B; b0 += 32) {     // the recurrence advances up to 32 utterances together
-      const int nb = std::min(32, B - b0);
-      int lmax = 0;
-      for (int b = b0; b < b0 + nb; ++b) lmax = std::max(lmax, 3 * m->T[b]);
-      HIP_TRY(pfhip::launch_blstm(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), d_off + b0, d_len + b0, nb, lmax, s));
+    // The recurrence advances up to 32 utterances together.  First the persistent kernel (one launch, 9 us per step); if its
+    // step barrier could not be served — the 32 blocks of a direction were not co-resident on one XCD because other work holds
+    // CUs there — the request is NOT failed: the same recurrence is redone as one launch per step (blstm.hip), which needs no
+    // co-residency and gives the same values bit for bit.  PFHIP_BLSTM_STEPWISE=1 skips the persistent attempt.
+    static const bool force_stepwise = [] { const char* e = getenv("PFHIP_BLSTM_STEPWISE"); return e && e[0] == '1'; }();
+    auto recurrence = [&](bool stepwise) -> pfhip_status {
+      for (int b0 = 0; b0 < B; b0 += 32) {
+        const int nb = std::min(32, B - b0);
+        int lmax = 0;
+        for (int b = b0; b < b0 + nb; ++b) lmax = std::max(lmax, 3 * m->T[b]);
+        if (stepwise)
+          HIP_TRY(pfhip::launch_blstm_stepwise(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), m->ts_cst.f(), d_off + b0, d_len + b0, nb,
+                                               lmax, s));
+        else
+          HIP_TRY(pfhip::launch_blstm(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), d_off + b0, d_len + b0, nb, lmax, s));
+      }
+      return PFHIP_OK;
+    };
+    HIP_TRY(m->ts_cst.ensure((size_t)2 * 32 * 512 * 4));
+    bool stepwise = force_stepwise;
+    if (!stepwise) {
+      pfhip_status st = recurrence(false);
+      if (st) return st;
+      unsigned flag = 0;
+      HIP_TRY(hipMemcpyAsync(&flag, m->ts_hx.f() + pfhip::kBlstmFlagWord, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (flag) {
+        HIP_TRY(hipMemsetAsync(m->ts_hx.f() + pfhip::kBlstmFlagWord, 0, 4, s));
+        ++m->blstm_fallbacks;
+        stepwise = true;
+      }
+    }
+    if (stepwise) {
+      pfhip_status st = recurrence(true);
+      if (st) return st;
     }
     pfhip::launch_alpha2(m->ts_y.f(), 2 * d, m->W("pred.out2.w").d, m->out2_b, c.smooth_factor2, c.noise_threshold2,
                          m->ts_a2.f(), R, 2 * d, s);
@@ -705,11 +735,6 @@ pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
                          m->ts_peaks.f(), s);
   }
   HIP_TRY(hipGetLastError());
-  unsigned flag = 0;
-  HIP_TRY(hipMemcpyAsync(&flag, m->ts_hx.f() + pfhip::kBlstmFlagWord, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (flag) return fail(PFHIP_ERR_HIP, flag == 2 ? "BLSTM: blocks of one direction were not placed on one XCD (results would be incoherent)"
-                                                 : "BLSTM: step barrier timed out");
   m->have_ts = true;
   return PFHIP_OK;
 }
@@ -903,7 +928,7 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->kvside})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->kvside, &m->ts_cst})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
@@ -1183,12 +1208,13 @@ pfhip_status pfhip_get_tensor(pfhip_model* m, const char* name, float* dst, size
 }
 
 // Test hook.  "blstm_flag" != 0: the next timestamp request finds the BLSTM error word raised (as after a step-barrier
-// time-out) and fails; the request after it must succeed again.
+// time-out) and must fall back to the per-step recurrence; "blstm_fallbacks" returns how often that happened (as the status).
 pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
   g_err.clear();
   if (!m || !what) return fail(PFHIP_ERR_ARG, "bad argument");
   std::lock_guard<std::mutex> lk(m->mu);
   if (std::string(what) == "blstm_flag") { m->debug_blstm_flag = value; return PFHIP_OK; }
+  if (std::string(what) == "blstm_fallbacks") return (pfhip_status)m->blstm_fallbacks;      // read-out: how often the per-step form ran
   return fail(PFHIP_ERR_ARG, std::string("unknown debug key ") + what);
 }
 

@@ -315,7 +315,8 @@ int pfhip_group_size(const pfhip_model* m);
 pfhip_status pfhip_group_stats(pfhip_model* m, int* devices, int64_t* calls, int64_t* utterances, int* open_streams, int cap);
 
 /* Test hook, not part of the serving path: "blstm_flag" (value != 0) raises the timestamp head's error word for the next
- * timestamp request only, which then fails with PFHIP_ERR_HIP; later requests are unaffected. */
+ * timestamp request only — as a step-barrier time-out of the persistent BLSTM kernel would — which then has to be served by the
+ * per-step recurrence; "blstm_fallbacks" returns (as the status value) how many requests were served that way. */
 pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value);
 pfhip_status pfhip_profile_enable(pfhip_model* m, int on);
 pfhip_status pfhip_profile_read(pfhip_model* m, pfhip_profile* out, int reset);

@@ -295,13 +295,17 @@ static bool att_x6_on() {
   return x6;
 }
 
+bool attention_fsmn_is_fused(int max_len) {
+  static const bool fuse = [] { const char* e = getenv("PFHIP_ATT_FSMN"); return !(e && e[0] == '0'); }();
+  return fuse && att_x6_on() && max_len > 64;
+}
+
 void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                            const int* off, const int* len, int B, int H, int max_len, float scale, const float* fsmn_w, float* mem,
-                           int ldmem, hipStream_t s) {
+                           int ldmem, hipStream_t s, bool mem_accumulate) {
   if (B <= 0 || max_len <= 0) return;
-  static const bool fuse = [] { const char* e = getenv("PFHIP_ATT_FSMN"); return !(e && e[0] == '0'); }();
-  if (fuse && att_x6_on() && max_len > 64) {
-    launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem);
+  if (attention_fsmn_is_fused(max_len)) {
+    launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
     return;
   }
   launch_fsmn(V, ldv, fsmn_w, nullptr, 0, mem, ldmem, off, len, B, max_len, H * kHeadDim, s);

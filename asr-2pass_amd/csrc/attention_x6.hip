@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
     const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
     float* __restrict__ O, int ldo, const int* __restrict__ q_off, const int* __restrict__ q_len,
     const int* __restrict__ kv_off, const int* __restrict__ kv_len, float scale, const float* __restrict__ fsmn_w,
-    float* __restrict__ mem, int ldmem) {
+    float* mem, int ldmem, int mem_accumulate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int b = blockIdx.y, head = blockIdx.x;
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
   // only: q rows = kv rows): mem[t][c] = v[t][c] + sum_j w[c][j] v[t + j - 5][c], zero outside the utterance — the fsmn_kernel of
   // rowops.hip (same operation order: bit-identical), folded in here because the (head, utterance, query block) grid covers
   // every (row, channel) exactly once and the V rows are about to be streamed anyway.  One launch and one 16.9-us kernel per
-  // encoder layer less; costs this workgroup ~2 us of its ~86.
+  // encoder layer less.  With mem_accumulate the memory is added straight into the residual stream (mem = x): the output
+  // projection that follows — bandwidth-bound at N = K = 512: 128 MB of operand, two residuals and result per 8.4 GFLOP — then
+  // reads one residual instead of two; the 33 MB move into this kernel, which has bandwidth to spare.
   if (fsmn_w) {
     constexpr int kTaps = 11, kStrip = 16;
     const int cg = tid & 31, strip = tid >> 5;
@@ -101,7 +103,12 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
             a.w += wk[3][j] * rows[s + j].w;
           }
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-          *reinterpret_cast<float4*>(mem + (kbase + t) * ldmem + c) = o;
+          float4* dst = reinterpret_cast<float4*>(mem + (kbase + t) * ldmem + c);
+          if (mem_accumulate) {            // mem IS the residual stream: x += memory (each element has exactly one owner)
+            const float4 xo = *dst;
+            o.x += xo.x; o.y += xo.y; o.z += xo.z; o.w += xo.w;
+          }
+          *dst = o;
         }
       }
     }
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
 
 void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
-                         float scale, hipStream_t s, const float* fsmn_w, float* mem, int ldmem) {
+                         float scale, hipStream_t s, const float* fsmn_w, float* mem, int ldmem, bool mem_accumulate) {
   if (B <= 0 || max_q_len <= 0) return;
   static std::atomic<unsigned long long> attr_done{0};      // > 64 KB of dynamic LDS needs the opt-in once per device
   int dev = 0;
@@ -386,7 +393,7 @@ void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const
   }
   const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(512);
   hipLaunchKernelGGL(attention_x6_kernel, grid, block, kLdsBytes, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
-                     kv_len, scale, fsmn_w, mem, ldmem);
+                     kv_len, scale, fsmn_w, mem, ldmem, mem_accumulate ? 1 : 0);
 }
 
 }  // namespace pfhip

@@ -105,12 +105,16 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
 // mem = V + depthwise conv k = 11 over time (what launch_fsmn computes, bit for bit) for its rows and its head's channels
 void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
-                         float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0);
+                         float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0,
+                         bool mem_accumulate = false);
 // Encoder-layer pair: FSMN memory of V (into mem) + self-attention (into O).  One launch where the BF16 attention kernel runs
 // (d_k = 128, more than 64 queries per utterance), otherwise launch_fsmn + launch_attention.  C = V's channel count (H * 128).
 void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                            const int* off, const int* len, int B, int H, int max_len, float scale, const float* fsmn_w, float* mem,
-                           int ldmem, hipStream_t s);
+                           int ldmem, hipStream_t s, bool mem_accumulate = false);
+// whether launch_attention_fsmn will be the single fused launch (then, and only then, mem_accumulate is honoured: the caller may
+// pass the residual stream as `mem` and drop the memory term from the output projection)
+bool attention_fsmn_is_fused(int max_len);
 void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                              const int* q_off, const int* q_len, const int* kv_off, const int* kv_len,
                              const int* q_kv_limit, int B, int H, int max_q_len, float scale, int head_dim, hipStream_t s);

@@ -448,6 +448,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   // epilogue; the GEMM that reads it (FFN1, the next layer's QKV) normalises its operand rows while staging them, with
   // gamma / beta folded into its weights (build_model).  One [M, 512] write + read and one launch per LayerNorm less.
   const bool fuse_ln = m->d_lnw_qkv != nullptr && pfhip::gemm_x6_ln_ok(M);
+  const bool mem_in_x = pfhip::attention_fsmn_is_fused(m->maxT);
   if (fuse_ln) HIP_TRY(m->lnstats.ensure((size_t)Mp * 4 * 2 * 4));
   auto gemm_ln = [&](const float* A, const float* Wd, int N, float* Cd, int ldc, const float* bias, const float* R1, const float* R2,
                      bool relu, bool ln_in, bool stats_out, int K) {
@@ -471,19 +472,23 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     {
       // FSMN memory of V + self-attention: one launch where the BF16 attention kernel runs (attention_x6.hip), else two
       Scope sc(m, s, K_ATTN, 4.0 * attn_pairs * d + 2.0 * 11 * M * d, 24.0 * M * d);
+      // fused launch: the FSMN memory goes straight into the residual stream (x += memory; x = memory in the first layer, which
+      // has no residual), so the bandwidth-bound output projection reads ONE residual
       pfhip::launch_attention_fsmn(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, m->m_row_off,
-                                   m->m_len, B, c.n_head, m->maxT, att_scale, m->W(p + "fsmn.w").d, m->mem.f(), d, s);
+                                   m->m_len, B, c.n_head, m->maxT, att_scale, m->W(p + "fsmn.w").d, mem_in_x ? x : m->mem.f(), d, s,
+                                   mem_in_x && !first);
     }
     // x = (first ? 0 : x) + ctx*Wo + b + fsmn_memory
     if (fuse_ln) {
-      gemm_ln(m->ctx.f(), m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, m->mem.f(), first ? nullptr : x, false, false, true, d);
+      gemm_ln(m->ctx.f(), m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, mem_in_x ? x : m->mem.f(), mem_in_x || first ? nullptr : x, false,
+              false, true, d);
       gemm_ln(x, m->d_lnw_ffn1 + (size_t)i * c.ffn * d, c.ffn, m->hbuf.f(), c.ffn, m->d_lnb_ffn1 + (size_t)i * c.ffn, nullptr, nullptr, true,
               true, false, d);
       gemm_ln(m->hbuf.f(), m->W(p + "ffn2.w").d, d, x, d, m->W(p + "ffn2.b").d, x, nullptr, false, false, i + 1 < c.enc_layers, c.ffn);
       continue;
     }
-    gemm(m, s, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
-         first ? nullptr : x, d, M, false);
+    gemm(m, s, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, mem_in_x ? x : m->mem.f(), d,
+         mem_in_x || first ? nullptr : x, d, M, false);
     lnorm(m, s, x, d, m->y.f(), d, p + "norm2", M, d, d);
     gemm(m, s, m->y.f(), d, m->W(p + "ffn1.w").d, c.ffn, d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0,
          nullptr, 0, M, true);

@@ -35,6 +35,15 @@ struct FbankParams {
 
 constexpr int kFrameLen = 400, kFrameShift = 160, kNfft = 512, kMels = 80, kLfrM = 7, kLfrN = 6;
 
+// Each wave owns its slices of the LDS arrays (xs / za / zb / ps [wave]): exchanges between its lanes need no workgroup
+// barrier.  A wave's LDS instructions execute in program order, so a ds_write followed by another lane's ds_read is ordered by
+// the hardware; the fence only stops the COMPILER from moving LDS accesses across it.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void fbank_lfr_cmvn_kernel(FbankParams p) {
     const int i = lane + 64 * j;
     if (i < kFrameLen) xs[wave][i] = v[j] - mean;
   }
-  __syncthreads();
+  wave_sync();
   // ---- pre-emphasis + window ---------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
@@ -92,11 +101,11 @@ __global__ __launch_bounds__(256) void fbank_lfr_cmvn_kernel(FbankParams p) {
     }
     v[j] = y;
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int j = 0; j < 7; ++j) xs[wave][lane + 64 * j] = v[j];
   xs[wave][448 + lane] = 0.f;
-  __syncthreads();
+  wave_sync();
 
   // ---- 512-pt real FFT as a 256-pt complex Stockham FFT in fp64 -------------------------------------
 #pragma unroll
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void fbank_lfr_cmvn_kernel(FbankParams p) {
     const int n = lane + 64 * q;
     za[wave][n] = make_double2((double)xs[wave][2 * n], (double)xs[wave][2 * n + 1]);
   }
-  __syncthreads();
+  wave_sync();
   double2* X = za[wave];
   double2* Y = zb[wave];
   const double2* tw = reinterpret_cast<const double2*>(p.tb.tw512);
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256) void fbank_lfr_cmvn_kernel(FbankParams p) {
       Y[q + sstr * (2 * pidx)] = make_double2(a.x + c.x, a.y + c.y);
       Y[q + sstr * (2 * pidx + 1)] = cmul(make_double2(a.x - c.x, a.y - c.y), w);
     }
-    __syncthreads();
+    wave_sync();
     double2* tmp = X; X = Y; Y = tmp;
   }
   // ---- split into the real-input spectrum, cast to fp32, power ----------------------------------
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void fbank_lfr_cmvn_kernel(FbankParams p) {
     const float im = (float)(e.y + xo.y);
     ps[wave][k] = re * re + im * im;
   }
-  __syncthreads();
+  wave_sync();
 
   // ---- mel + log -----------------------------------------------------------------------------
   float melv[2];

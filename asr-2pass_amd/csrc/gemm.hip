@@ -724,10 +724,16 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
                               column_group_width(M, K, (N + kTileN - 1) / kTileN), s);
     return;
   }
-  if (kind == 4 || kind == 5 || (kind == 0 && x6_on && tiles >= 128)) {
-    const bool small_tile = kind == 5 || (kind == 0 && !(K >= 1024 && tiles256 >= 180));
+  // (tools/gemm_small_probe.py: between 48 and 160 tiles of 128 x 128 the half-height BF16-split kernel beats both the fp32-MFMA
+  // 64-row kernel and the 128 x 128 BF16-split kernel by 15-25 % — 1-5 utterances of 30 s, rounds of 25-128 streaming connections)
+  if (kind == 4 || kind == 5 || kind == 7 || (kind == 0 && x6_on && tiles >= 48)) {
+    const bool small_tile = kind == 5 || kind == 7 || (kind == 0 && !(K >= 1024 && tiles256 >= 180));
+    // measured (tools/gemm_x6_probe.py SHAPES=dec, kinds 5 vs 7): the half-height tile wins only while the 128 x 128 grid
+    // leaves most CUs with a single workgroup (<= 160 tiles: 19.8 vs 23.9 us at M = 4000, N = K = 512); from 220 tiles on the
+    // taller tile is ahead again (28.3 vs 31.1 us at M = 7015)
+    const bool half_tile = kind == 7 || (kind == 0 && small_tile && tiles <= 160);
     launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                           column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile);
+                           column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, nullptr, 0, nullptr, half_tile);
     return;
   }
   const bool skinny = kind == 2 || (kind == 0 && tiles < kStreamingBelowTiles);

@@ -437,13 +437,174 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
   }
 }
 
+
+// ---- 64 x 128 sibling for grids between a quarter and three quarters of the chip's 512 workgroup slots — the decoder's
+// N = 512 launches over ML ~ 7000 token rows are 220 tiles of 128 x 128: one workgroup on 220 CUs, nothing to overlap its
+// prologue and epilogue with, 77 TF.  Half-height tiles double the count (two workgroups on most CUs).  8 waves as 2 x 4, each
+// ONE 32 x 32 MFMA tile; A is staged by waves 0-3 (64 rows), W by all (128 rows); LDS 2 x 27,648 B.  Per K-step and wave:
+// 6 MFMAs, 22-44 VALU ops of splitting, 3-6 LDS writes, 1-2 global loads, 6 fragment reads — more overhead per flop than the
+// 128 x 128 tile, which stays the choice wherever its grid fills the slots.
+constexpr int kHM = 64;
+constexpr int kHPlaneA = kHM * kRowB;                       // 3,072 B
+constexpr int kHPlaneW = kBN * kRowB;                       // 6,144 B
+constexpr int kHStageB = 3 * (kHPlaneA + kHPlaneW);         // 27,648 B
+constexpr int kHLdsBytes = 2 * kHStageB;                    // 55,296 B
+static_assert(kHM * kCs * 4 <= kHLdsBytes, "C tile must fit the operand buffers");
+
+template <bool LN>
+__global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
+    const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
+    int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  int tm, tn;
+  tile_of_block_x6(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
+  const int m0 = tm * kHM, n0 = tn * kBN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int srow = tid >> 2, sq = tid & 3;
+  const bool stage_a = srow < kHM;                           // waves 0-3 (wave-uniform)
+  const float* Ag = A + (size_t)min(m0 + (stage_a ? srow : 0), M - 1) * lda + 4 * sq;
+  const float* Wg = W + (size_t)min(n0 + srow, N - 1) * ldw + 4 * sq;
+  const int a_st = srow * kRowB + 8 * sq;
+  const int w_st = 3 * kHPlaneA + srow * kRowB + 8 * sq;
+  const int a_fr = (wr * 32 + r) * kRowB + 16 * h;
+  const int w_fr = 3 * kHPlaneA + (wc * 32 + r) * kRowB + 16 * h;
+
+  float ln_mean = 0.f, ln_rstd = 1.f;
+  if (LN && stage_a) {
+    const float* sp = ln_stats + (size_t)min(m0 + srow, M - 1) * ln_tiles * 2;
+    float msum = 0.f, m2 = 0.f;
+    for (int t = 0; t < ln_tiles; ++t) msum += sp[2 * t];
+    ln_mean = msum / (float)ln_tiles;
+    for (int t = 0; t < ln_tiles; ++t) { const float dm = sp[2 * t] - ln_mean; m2 += sp[2 * t + 1] + (float)kBN * dm * dm; }
+    ln_rstd = 1.0f / sqrtf(m2 / (float)(ln_tiles * kBN) + ln_eps);
+  }
+
+  float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xw, ya = xa, yw;
+#define PFHIP_LOAD_RAW(RA, RW, k0)                                           \
+  if (stage_a) RA = *reinterpret_cast<const float4*>(Ag + (k0));             \
+  RW = *reinterpret_cast<const float4*>(Wg + (k0));
+  auto split3 = [&](const float4& v, unsigned char* base, int plane_bytes) {
+    uint2 p;
+    p.x = top16_pair(v.x, v.y); p.y = top16_pair(v.z, v.w);
+    *reinterpret_cast<uint2*>(base) = p;
+    float4 s = make_float4(rest(v.x), rest(v.y), rest(v.z), rest(v.w));
+    p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
+    *reinterpret_cast<uint2*>(base + plane_bytes) = p;
+    s = make_float4(rest(s.x), rest(s.y), rest(s.z), rest(s.w));
+    p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
+    *reinterpret_cast<uint2*>(base + 2 * plane_bytes) = p;
+  };
+  auto ln_apply = [&](const float4& v) {
+    return make_float4((v.x - ln_mean) * ln_rstd, (v.y - ln_mean) * ln_rstd, (v.z - ln_mean) * ln_rstd, (v.w - ln_mean) * ln_rstd);
+  };
+#define PFHIP_SPLIT_STORE(RA, RW, stage)                                                              \
+  if (stage_a) split3(LN ? ln_apply(RA) : RA, lds + (stage) * kHStageB + a_st, kHPlaneA);             \
+  split3(RW, lds + (stage) * kHStageB + w_st, kHPlaneW);
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  bf16x8 fa[3], fb[3], ga[3], gb[3];
+#define PFHIP_FRAGS(FA, FB, stage)                                                                                  \
+  _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
+    FA[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kHStageB + p * kHPlaneA + a_fr)); \
+    FB[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (stage) * kHStageB + p * kHPlaneW + w_fr)); \
+  }
+#define PFHIP_X6(FA, FB, pa, pb) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa], FB[pb], acc, 0, 0, 0);
+#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, nxt, knext)                                        \
+  PFHIP_SPLIT_STORE(RA, RW, nxt)                                                              \
+  PFHIP_LOAD_RAW(RA, RW, knext)                                                               \
+  PFHIP_X6(FA, FB, 1, 1) PFHIP_X6(FA, FB, 0, 2) PFHIP_X6(FA, FB, 2, 0) PFHIP_X6(FA, FB, 0, 1)  \
+  __builtin_amdgcn_sched_barrier(0);                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
+  __builtin_amdgcn_sched_barrier(0);                                                          \
+  PFHIP_FRAGS(GA, GB, nxt)                                                                    \
+  PFHIP_X6(FA, FB, 1, 0) PFHIP_X6(FA, FB, 0, 0)                                               \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int nk = K / kBK;
+  auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
+  PFHIP_LOAD_RAW(xa, xw, 0)
+  PFHIP_SPLIT_STORE(xa, xw, 0)
+  PFHIP_LOAD_RAW(ya, yw, kclamp(1))
+  PFHIP_LOAD_RAW(xa, xw, kclamp(2))
+  __syncthreads();
+  PFHIP_FRAGS(fa, fb, 0)
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    { const int knext = kclamp(kt + 3); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
+    { const int knext = kclamp(kt + 4); PFHIP_STEP(ga, gb, fa, fb, xa, xw, 0, knext) }
+  }
+  if (kt < nk) { const int knext = kclamp(nk); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
+#undef PFHIP_STEP
+#undef PFHIP_SPLIT_STORE
+#undef PFHIP_LOAD_RAW
+#undef PFHIP_X6
+#undef PFHIP_FRAGS
+  __syncthreads();
+
+  float* const Cs = reinterpret_cast<float*>(lds);
+  {
+    float* cw = Cs + (wr * 32 + 4 * h) * kCs + wc * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cw[((e & 3) + 8 * (e >> 2)) * kCs] = acc[e];
+  }
+  __syncthreads();
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    else {
+      if (gcol < N) bv.x = bias[gcol];
+      if (gcol + 1 < N) bv.y = bias[gcol + 1];
+      if (gcol + 2 < N) bv.z = bias[gcol + 2];
+    }
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 16 + rsub;
+    const int grow = m0 + row;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (grow < M && gcol + 3 < N) {
+      if (R1) {
+        const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (R2) {
+        const float4 t = *reinterpret_cast<const float4*>(R2 + (size_t)grow * ldr2 + gcol);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+    } else if (grow < M && gcol < N) {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int q = 0; q < 4 && gcol + q < N; ++q) {
+        float o = vv[q];
+        if (R1) o += R1[(size_t)grow * ldr1 + gcol + q];
+        if (R2) o += R2[(size_t)grow * ldr2 + gcol + q];
+        if (relu) o = fmaxf(o, 0.f);
+        C[(size_t)grow * ldc + gcol + q] = o;
+      }
+    }
+    if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
+  }
+}
+
 }  // namespace
 
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
-                            const float* ln_stats, int ln_tiles, float* stats_out) {
+                            const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile) {
   if (M <= 0 || N <= 0) return;
-  if (ln_stats) small_tile = true;              // LayerNorm-on-load lives in the 128 x 128 kernel (its consumers have K = 512)
+  if (ln_stats) small_tile = true;              // LayerNorm-on-load lives in the 128 / 64-row kernels (its consumers have K = 512)
   // > 64 KB of dynamic LDS needs the opt-in once per device
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -455,7 +616,22 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
                               kSLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kSLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kHLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bf16x6_64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kHLdsBytes);
     attr_done.fetch_or(1ull << (dev & 63));
+  }
+  if (small_tile && half_tile) {
+    const int tiles_m = (M + kHM - 1) / kHM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;
+    gw = std::max(1, std::min(gw, tiles_n));
+    if (ln_stats)
+      hipLaunchKernelGGL(gemm_f32_bf16x6_64_kernel<true>, dim3(n_tiles), dim3(512), kHLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+    else
+      hipLaunchKernelGGL(gemm_f32_bf16x6_64_kernel<false>, dim3(n_tiles), dim3(512), kHLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+    return;
   }
   if (small_tile) {
     const int tiles_m = (M + kSM - 1) / kSM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;

@@ -59,7 +59,7 @@ void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C,
 // beta into the bias by the caller.
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile = false,
-                            const float* ln_stats = nullptr, int ln_tiles = 0, float* stats_out = nullptr);
+                            const float* ln_stats = nullptr, int ln_tiles = 0, float* stats_out = nullptr, bool half_tile = false);
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).

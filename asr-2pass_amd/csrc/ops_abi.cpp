@@ -20,7 +20,7 @@ int pfhip_op_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C
 int pfhip_op_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                            const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
                            int guard, int kind, void* stream) {
-  if (K % pfhip::kTileK || kind < 0 || kind > 6) return (int)hipErrorInvalidValue;
+  if (K % pfhip::kTileK || kind < 0 || kind > 7) return (int)hipErrorInvalidValue;
   pfhip::launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu != 0, guard != 0, kind, S(stream));
   return done();
 }

@@ -2,6 +2,7 @@
 //   host_selftest mergequeue <threads> <rounds>     stress of merge_queue.h: every request served exactly once, merged batches
 //   host_selftest tokenize <tokens.json> [manifest]  stdin lines -> "n | w0 w1 ... | id0 id1 ..." (PuncTokenizerHip::Tokenize)
 //   host_selftest jsonstrings <file>                 prints the strings of the first JSON array, one per line, as hex bytes
+//   host_selftest hotwords <tokens.json> <seg_dict|->   stdin lines of hotword strings -> "n | len ... | id ..." (HotwordIdMatrix)
 //   host_selftest vocabtext <tokens.json> [language]  stdin lines of ids -> HostVocab::Vector2StringV2 of each line (ONE object:
 //                                                     the end-of-call memory carries over), as hex bytes
 #include <atomic>
@@ -17,6 +18,7 @@
 #include "../merge_queue.h"
 #include "ct_transformer_hip.h"
 #include "host_vocab.h"
+#include "hotword_text.h"
 #include "json_strings.h"
 
 namespace {
@@ -91,6 +93,23 @@ int main(int argc, char** argv) {
     }
     std::printf("punc %s %s %s %s %s %s ispunc %d %d\n", tk.Id2Punc(0).c_str(), tk.Id2Punc(1).c_str(), tk.Id2Punc(2).c_str(),
                 tk.Id2Punc(3).c_str(), tk.Id2Punc(4).c_str(), tk.Id2Punc(5).c_str(), (int)tk.IsPunc(tk.Id2Punc(3)), (int)tk.IsPunc("x"));
+    return 0;
+  }
+  if (cmd == "hotwords" && argc >= 4) {
+    pfhip_host::HostVocab vocab;
+    if (!vocab.Load(argv[2])) { std::fprintf(stderr, "cannot open tokens\n"); return 1; }
+    pfhip_host::SegDictHost dict;
+    const bool have_dict = std::string(argv[3]) != "-" && dict.Load(argv[3]);
+    std::string line;
+    while (std::getline(std::cin, line)) {
+      std::vector<int> mat, lens;
+      pfhip_host::HotwordIdMatrix(line, have_dict ? &dict : nullptr, [&](const std::string& u) { return vocab.GetIdByToken(u); }, mat, lens);
+      std::printf("%zu |", lens.size());
+      for (int l : lens) std::printf(" %d", l);
+      std::printf(" |");
+      for (int v : mat) std::printf(" %d", v);
+      std::printf("\n");
+    }
     return 0;
   }
   if (cmd == "vocabtext" && argc >= 3) {

@@ -29,6 +29,7 @@ ParaformerHip::ParaformerHip() {
 ParaformerHip::~ParaformerHip() {
   if (handle_) pfhip_destroy(handle_);
   delete vocab;
+  delete seg_dict_;
 #ifdef PFHIP_WITH_FUNASR
   delete lm_vocab;
   delete phone_set_;
@@ -203,45 +204,22 @@ std::vector<std::string> ParaformerHip::Forward(float** din, int* len, bool inpu
   return results;
 }
 
-namespace {
-// UTF-8 code points of s, one string each
-std::vector<std::string> Utf8Chars(const std::string& s) {
-  std::vector<std::string> out;
-  for (size_t i = 0; i < s.size();) {
-    const unsigned char c = (unsigned char)s[i];
-    const size_t n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 1;
-    out.push_back(s.substr(i, n));
-    i += n;
-  }
-  return out;
+void ParaformerHip::InitSegDict(const std::string& seg_dict_model) {
+  delete seg_dict_;
+  seg_dict_ = new pfhip_host::SegDictHost();
+  if (!seg_dict_->Load(seg_dict_model.c_str())) std::fprintf(stderr, "%s open failed !!\n", seg_dict_model.c_str());     // seg_dict.cpp:22-25
 }
-}  // namespace
 
 std::vector<std::vector<float>> ParaformerHip::CompileHotwordEmbedding(std::string& hotwords) {
   const int d = handle_ ? pfhip_d_model(handle_) : 512;
   if (!handle_ || !pfhip_is_contextual(handle_)) return {std::vector<float>(d, 0.f)};      // paraformer.cpp:594-599
-  const int kMaxLen = 10;                                                                 // :629
-  std::vector<int32_t> mat, lens;
-  std::stringstream ss(hotwords);
-  std::string word;
-  while (ss >> word) {
-    std::vector<int32_t> row;
-    bool known = true;
-    for (const std::string& ch : Utf8Chars(word)) {
-      int id = -1;
-      if (vocab) id = vocab->GetIdByToken(ch);
-      if (id < 0) { known = false; break; }       // the reference drops a hotword with an out-of-vocabulary unit (:634-640)
-      if ((int)row.size() < kMaxLen) row.push_back(id);
-    }
-    if (!known || row.empty()) continue;
-    lens.push_back((int32_t)row.size());
-    row.resize(kMaxLen, 0);
-    mat.insert(mat.end(), row.begin(), row.end());
-  }
-  { std::vector<int32_t> last(kMaxLen, 0); last[0] = 1; mat.insert(mat.end(), last.begin(), last.end()); lens.push_back(1); }   // :648-651
+  std::vector<int> mat, lens;
+  pfhip_host::HotwordIdMatrix(hotwords, seg_dict_, [&](const std::string& unit) { return vocab ? vocab->GetIdByToken(unit) : -1; }, mat,
+                              lens);                                                      // :600-651
   const int H = (int)lens.size();
+  std::vector<int32_t> mat32(mat.begin(), mat.end()), lens32(lens.begin(), lens.end());
   std::vector<float> emb((size_t)H * d);
-  if (pfhip_hotword_embed(handle_, mat.data(), lens.data(), H, emb.data()) != PFHIP_OK) {
+  if (pfhip_hotword_embed(handle_, mat32.data(), lens32.data(), H, emb.data()) != PFHIP_OK) {
     std::fprintf(stderr, "ParaformerHip::CompileHotwordEmbedding: %s\n", pfhip_last_error());
     return {std::vector<float>(d, 0.f)};
   }

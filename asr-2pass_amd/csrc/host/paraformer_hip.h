@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../../include/pfhip.h"
+#include "hotword_text.h"
 
 #ifdef PFHIP_WITH_FUNASR
 #include "model.h"
@@ -44,6 +45,8 @@ class ParaformerHipBase {
   virtual std::vector<std::string> Forward(float** din, int* len, bool input_finished,
                                            const std::vector<std::vector<float>>& hw_emb = {{0.0}}, void* wfst_decoder = nullptr,
                                            int batch_in = 1) { return std::vector<std::string>(); }
+  virtual void InitHwCompiler(const std::string& hw_model, int thread_num) {}
+  virtual void InitSegDict(const std::string& seg_dict_model) {}
   virtual std::vector<std::vector<float>> CompileHotwordEmbedding(std::string& hotwords) { return {}; }
   virtual std::string Rescoring() = 0;
   virtual std::string GetLang() { return ""; }
@@ -98,11 +101,14 @@ class ParaformerHip : public ParaformerHipBase
   std::vector<std::string> Forward(float** din, int* len, bool input_finished,
                                    const std::vector<std::vector<float>>& hw_emb = {{0.0}}, void* wfst_decoder = nullptr,
                                    int batch_in = 1) override;
-  // Plain model: one zero row of encoder_size, as Paraformer::CompileHotwordEmbedding does when
-  // use_hotword is false (paraformer.cpp:594-599).  Contextual model: whitespace-separated hotwords, each split into
-  // vocabulary units (UTF-8 characters looked up in tokens.json; the reference additionally consults seg_dict for
-  // Latin words, :601-647 — host text handling, not restated), at most 10 ids each, the [1,0,...] row appended
-  // (:648-651), then the device embedder (pfhip_hotword_embed).
+  // offline-stream.cpp:65-71: the hotword embedder's weights live in the same container as the acoustic model (bias.* tensors),
+  // so InitHwCompiler has nothing to load; InitSegDict reads the "word<TAB>pieces" file Latin hotwords are segmented with.
+  void InitHwCompiler(const std::string& hw_model, int thread_num) override { (void)hw_model; (void)thread_num; }
+  void InitSegDict(const std::string& seg_dict_model) override;
+  // Plain model: one zero row of encoder_size, as Paraformer::CompileHotwordEmbedding does when use_hotword is false
+  // (paraformer.cpp:594-599).  Contextual model: the reference's string handling (hotword_text.h: space-separated hotwords,
+  // all-Chinese ones split into characters, the others through the segmentation dictionary, at most 10 units, out-of-vocabulary
+  // hotwords dropped, the [1,0,...] row appended, :600-651), then the device embedder (pfhip_hotword_embed).
   std::vector<std::vector<float>> CompileHotwordEmbedding(std::string& hotwords) override;
   void StartUtterance() override {}
   void EndUtterance() override {}
@@ -149,6 +155,7 @@ class ParaformerHip : public ParaformerHipBase
   int batch_size_ = 1;
   bool has_lm_ = false;
   HipVocab* vocab = nullptr;               // tokens.json (paraformer.cpp:47-48)
+  pfhip_host::SegDictHost* seg_dict_ = nullptr;
 };
 
 }  // namespace funasr

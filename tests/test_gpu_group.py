@@ -112,3 +112,46 @@ def test_env_var_builds_the_group_for_an_unchanged_caller(weights_mod, tmp_path)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GROUP 2 [2, 2]" in out.stdout
+
+
+def test_c5_long_audio_workers_over_a_replica_group(pkg, weights_mod):
+    """BASELINE configs[4] in miniature: 8 concurrent decoder workers, each transcribing a VAD-segmented long file through ONE
+    shared handle that fronts several replicas (here two on device 0; on an 8-GPU node PFHIP_DEVICES=0,...,7): every worker's
+    segments and ids equal the single-model, single-thread flow; both replicas served calls."""
+    import importlib
+    from test_gpu_pipeline import make_file, shape_vad_weights
+    pipeline = importlib.import_module("asr_2pass_amd.pipeline")
+    vman, vblob = shape_vad_weights(*weights_mod.synth_vad_weights())
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=1, vocab=300)
+    aman, ablob = weights_mod.synth_weights(cfg)
+    files = [make_file(np.random.default_rng(100 + i)) for i in range(8)]
+    vad = pkg.FsmnVadHip().InitVad((vman, vblob))
+    single = pkg.ParaformerHip().InitAsr((aman, ablob))
+    want = []
+    for f in files:
+        seg = pkg.E2EVadModelHost()
+        want.append(pipeline.infer_buffer(f, single, vad, seg, batch_size=4, vad_max_len=60000))
+        seg.close()
+    single.close()
+    group = pkg.ParaformerHip().InitAsr((aman, ablob), devices=[0, 0])
+    group.set_batching(2000, 32)                   # the server's shape: decoder threads share the handle, calls are merged per replica
+    got = [None] * 8
+    vads = [pkg.FsmnVadHip().InitVad((vman, vblob)) for _ in range(8)]
+
+    def worker(i):
+        seg = pkg.E2EVadModelHost()
+        got[i] = pipeline.infer_buffer(files[i], group, vads[i], seg, batch_size=4, vad_max_len=60000)
+        seg.close()
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(8):
+        assert got[i][1] == want[i][1], i                                   # segments
+        assert [list(x) for x in got[i][0]] == [list(x) for x in want[i][0]], i      # ids per segment
+    st = group.group_stats()
+    assert min(st["calls"]) > 0 and sum(st["utterances"]) == sum(len(w[1]) for w in want)
+    group.close(); vad.close()
+    for v in vads:
+        v.close()

@@ -259,6 +259,9 @@ def main():
                 # so its ceiling is the BF16 dense peak / 6 (executed MFMA rate = 6 x achieved, against 2500)
                 "bound": "mfma", "kernel": "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel", "achieved": ach, "peak": X6_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / X6_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                "note": "flops counted = 2*M*N*K of the GEMMs only; since round 2 the same launches also carry the encoder's "
+                        "LayerNorms (row statistics in the producing epilogue, normalisation on load in the consumer), so the class "
+                        "does more work per counted flop than in round 1 while the step got shorter",
                 "executed_mfma_tflops": ach * X6_MFMAS_PER_BLOCK, "executed_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": F32_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches_per_step": g["launches"] / args.steps,

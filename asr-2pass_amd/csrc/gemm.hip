@@ -763,12 +763,12 @@ bool gemm_x6_ln_ok(int M) {
 }
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
-                           float* stats_out, hipStream_t s) {
+                           const float* ln_colsum, float* stats_out, hipStream_t s) {
   if (M <= 0 || N <= 0) return;
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
   const bool small_tile = !(K >= 1024 && tiles256 >= 180);
   launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                         column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out);
+                         column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out, false, ln_colsum);
 }
 
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,

@@ -89,6 +89,22 @@ __device__ __forceinline__ void tile_row_stats(const float4& v, int grow, int M,
   if (c4 == 0 && grow < M) *reinterpret_cast<float2*>(stats + ((size_t)grow * tiles_n + tn) * 2) = make_float2(mean, q);
 }
 
+// the consumer's half.  Row statistics merged from the producer's per-tile pairs (Chan: n = 128 per tile) — one thread per row,
+// at kernel start, parked in registers under the K-loop and published through LDS for the epilogue passes ...
+__device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, int tiles, float eps, int row) {
+  const float* sp = stats + (size_t)row * tiles * 2;
+  float msum = 0.f, m2 = 0.f;
+  for (int t = 0; t < tiles; ++t) msum += sp[2 * t];
+  const float mean = msum / (float)tiles;
+  for (int t = 0; t < tiles; ++t) { const float dm = sp[2 * t] - mean; m2 += sp[2 * t + 1] + (float)kBN * dm * dm; }
+  return make_float2(mean, 1.0f / sqrtf(m2 / (float)(tiles * kBN) + eps));
+}
+// ... where v (four columns of x W'^T) becomes rstd * (v - mean * colsum)
+__device__ __forceinline__ void ln_finish(float4& v, const float4& cs, float2 mr) {
+  v.x = mr.y * (v.x - mr.x * cs.x); v.y = mr.y * (v.y - mr.x * cs.y);
+  v.z = mr.y * (v.z - mr.x * cs.z); v.w = mr.y * (v.w - mr.x * cs.w);
+}
+
 __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
@@ -277,7 +293,8 @@ template <bool LN>
 __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
-    int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out) {
+    int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
+    const float* __restrict__ ln_colsum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -295,19 +312,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
   const int a_fr = (wr * 64 + r) * kRowB + 16 * h;
   const int w_fr = 3 * kSPlane + (wc * 32 + r) * kRowB + 16 * h;
 
-  // LayerNorm on load (ln_stats != nullptr): the A operand is the raw residual stream; this thread's row is normalised as
-  // (x - mean) * rstd while it is staged — gamma is folded into the weights and beta into the bias by the caller.  mean / rstd
-  // come from the per-tile pairs the producing GEMM left (tile_row_stats), merged with Chan's formula (ln_tiles tiles of 128).
-  float ln_mean = 0.f, ln_rstd = 1.f;
-  if (LN) {
-    const float* sp = ln_stats + (size_t)min(m0 + srow, M - 1) * ln_tiles * 2;
-    float msum = 0.f, m2 = 0.f;
-    for (int t = 0; t < ln_tiles; ++t) msum += sp[2 * t];
-    ln_mean = msum / (float)ln_tiles;
-    for (int t = 0; t < ln_tiles; ++t) { const float dm = sp[2 * t] - ln_mean; m2 += sp[2 * t + 1] + (float)kBN * dm * dm; }
-    ln_rstd = 1.0f / sqrtf(m2 / (float)(ln_tiles * kBN) + ln_eps);
-  }
-
+  // LayerNorm folded in (LN): the A operand is the RAW residual stream x; with gamma folded into the weights (W' = W gamma)
+  //     LN(x) W^T = rstd_i * (x W'^T - mean_i * colsum(W')_n) + (bias + W beta)_n,
+  // so the K-loop is the plain one and the normalisation is two FMAs per output element in the epilogue (mean_i / rstd_i merged
+  // from the per-tile pairs the producing GEMM left, Chan's formula; colsum and the folded bias prepared at load).  The
+  // subtraction amplifies the accumulation error by about sqrt(mean^2 + var) / std of the row — a small factor for a residual
+  // stream — where normalising on load did not, but on-load cost the 4-waves-per-SIMD loop 4 % (8 VALU ops per K-step).
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (LN && tid < kSM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
   float4 xa, xw, ya, yw;
 #define PFHIP_LOAD_RAW(RA, RW, k0)                            \
   RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
@@ -323,11 +335,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
     p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
     *reinterpret_cast<uint2*>(base + 2 * kSPlane) = p;
   };
-  auto ln_apply = [&](const float4& v) {
-    return make_float4((v.x - ln_mean) * ln_rstd, (v.y - ln_mean) * ln_rstd, (v.z - ln_mean) * ln_rstd, (v.w - ln_mean) * ln_rstd);
-  };
 #define PFHIP_SPLIT_STORE(RA, RW, stage)                      \
-  split3(LN ? ln_apply(RA) : RA, lds + (stage) * kSStageB + a_st); \
+  split3(RA, lds + (stage) * kSStageB + a_st);                \
   split3(RW, lds + (stage) * kSStageB + w_st);
 
   f32x16 acc0, acc1;
@@ -394,6 +403,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
       cw[ro + 32 * kCs] = acc1[e];
     }
   }
+  float2* const s_mr = reinterpret_cast<float2*>(lds + kSM * kCs * 4);          // behind the C tile: 128 x (mean, rstd)
+  static_assert(kSM * kCs * 4 + kSM * 8 <= kSLdsBytes, "row statistics must fit behind the C tile");
+  if (LN && tid < kSM) s_mr[tid] = ln_mr;
   __syncthreads();
   const int c4 = tid & 31, rsub = tid >> 5;
   const int gcol = n0 + 4 * c4;
@@ -406,11 +418,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
       if (gcol + 2 < N) bv.z = bias[gcol + 2];
     }
   }
+  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
 #pragma unroll 2
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 16 + rsub;
     const int grow = m0 + row;
     float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+    if (LN) ln_finish(v, cs4, s_mr[row]);
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     if (grow < M && gcol + 3 < N) {
       if (R1) {
@@ -455,7 +470,8 @@ template <bool LN>
 __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
-    int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out) {
+    int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
+    const float* __restrict__ ln_colsum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -474,16 +490,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
   const int a_fr = (wr * 32 + r) * kRowB + 16 * h;
   const int w_fr = 3 * kHPlaneA + (wc * 32 + r) * kRowB + 16 * h;
 
-  float ln_mean = 0.f, ln_rstd = 1.f;
-  if (LN && stage_a) {
-    const float* sp = ln_stats + (size_t)min(m0 + srow, M - 1) * ln_tiles * 2;
-    float msum = 0.f, m2 = 0.f;
-    for (int t = 0; t < ln_tiles; ++t) msum += sp[2 * t];
-    ln_mean = msum / (float)ln_tiles;
-    for (int t = 0; t < ln_tiles; ++t) { const float dm = sp[2 * t] - ln_mean; m2 += sp[2 * t + 1] + (float)kBN * dm * dm; }
-    ln_rstd = 1.0f / sqrtf(m2 / (float)(ln_tiles * kBN) + ln_eps);
-  }
-
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
   float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xw, ya = xa, yw;
 #define PFHIP_LOAD_RAW(RA, RW, k0)                                           \
   if (stage_a) RA = *reinterpret_cast<const float4*>(Ag + (k0));             \
@@ -499,11 +507,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
     p.x = top16_pair(s.x, s.y); p.y = top16_pair(s.z, s.w);
     *reinterpret_cast<uint2*>(base + 2 * plane_bytes) = p;
   };
-  auto ln_apply = [&](const float4& v) {
-    return make_float4((v.x - ln_mean) * ln_rstd, (v.y - ln_mean) * ln_rstd, (v.z - ln_mean) * ln_rstd, (v.w - ln_mean) * ln_rstd);
-  };
 #define PFHIP_SPLIT_STORE(RA, RW, stage)                                                              \
-  if (stage_a) split3(LN ? ln_apply(RA) : RA, lds + (stage) * kHStageB + a_st, kHPlaneA);             \
+  if (stage_a) split3(RA, lds + (stage) * kHStageB + a_st, kHPlaneA);                                 \
   split3(RW, lds + (stage) * kHStageB + w_st, kHPlaneW);
 
   f32x16 acc;
@@ -555,6 +560,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) cw[((e & 3) + 8 * (e >> 2)) * kCs] = acc[e];
   }
+  float2* const s_mr = reinterpret_cast<float2*>(lds + kHM * kCs * 4);
+  static_assert(kHM * kCs * 4 + kHM * 8 <= kHLdsBytes, "row statistics must fit behind the C tile");
+  if (LN && tid < kHM) s_mr[tid] = ln_mr;
   __syncthreads();
   const int c4 = tid & 31, rsub = tid >> 5;
   const int gcol = n0 + 4 * c4;
@@ -567,11 +575,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
       if (gcol + 2 < N) bv.z = bias[gcol + 2];
     }
   }
+  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
 #pragma unroll 2
   for (int pass = 0; pass < 4; ++pass) {
     const int row = pass * 16 + rsub;
     const int grow = m0 + row;
     float4 v = *reinterpret_cast<const float4*>(Cs + row * kCs + 4 * c4);
+    if (LN) ln_finish(v, cs4, s_mr[row]);
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     if (grow < M && gcol + 3 < N) {
       if (R1) {
@@ -602,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
 
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
-                            const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile) {
+                            const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum) {
   if (M <= 0 || N <= 0) return;
   if (ln_stats) small_tile = true;              // LayerNorm-on-load lives in the 128 / 64-row kernels (its consumers have K = 512)
   // > 64 KB of dynamic LDS needs the opt-in once per device
@@ -627,10 +638,10 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
     gw = std::max(1, std::min(gw, tiles_n));
     if (ln_stats)
       hipLaunchKernelGGL(gemm_f32_bf16x6_64_kernel<true>, dim3(n_tiles), dim3(512), kHLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
-                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out, ln_colsum);
     else
       hipLaunchKernelGGL(gemm_f32_bf16x6_64_kernel<false>, dim3(n_tiles), dim3(512), kHLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
-                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out, ln_colsum);
     return;
   }
   if (small_tile) {
@@ -638,10 +649,10 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
     gw = std::max(1, std::min(gw, tiles_n));
     if (ln_stats)
       hipLaunchKernelGGL(gemm_f32_bf16x6_128_kernel<true>, dim3(n_tiles), dim3(512), kSLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
-                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out, ln_colsum);
     else
       hipLaunchKernelGGL(gemm_f32_bf16x6_128_kernel<false>, dim3(n_tiles), dim3(512), kSLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1,
-                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out);
+                         R2, ldr2, M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, stats_out, ln_colsum);
     return;
   }
   const int tiles_m = (M + kBM - 1) / kBM, tiles_n = (N + kBN - 1) / kBN, n_tiles = tiles_m * tiles_n;

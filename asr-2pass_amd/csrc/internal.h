@@ -129,6 +129,7 @@ struct pfhip_model {
   // LayerNorm folded into its consumer GEMM (gemm_x6.hip LN-on-load): per encoder layer W * gamma (per input column) and
   // bias + W beta, for qkv (layers >= 1) and ffn1; [layers][N][d] / [layers][N]
   float* d_lnw_qkv = nullptr; float* d_lnb_qkv = nullptr; float* d_lnw_ffn1 = nullptr; float* d_lnb_ffn1 = nullptr;
+  float* d_lns_qkv = nullptr; float* d_lns_ffn1 = nullptr;      // column sums of the folded weights [layers][N]
   // timestamp head repacks: ConvTranspose1d as [3d][d] + tiled bias, both LSTM directions' input weights [8d][d] + summed
   // biases, recurrent weights [2][4d][d]
   float* d_up_w = nullptr; float* d_up_b = nullptr; float* d_wih = nullptr; float* d_bih = nullptr; float* d_whh = nullptr;

@@ -54,19 +54,20 @@ void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C,
 // fp32-grade GEMM on the BF16 matrix cores (three-way bf16 split of both operands, six MFMAs per block): gemm_x6.hip
 // stats_out (N == tiles_n * 128 exactly): the epilogue also leaves per-row LayerNorm statistics of its 128-column tile at
 // stats_out[row][tile column][2] = (mean of the tile's columns, sum of squared deviations from it).
-// ln_stats (with ln_tiles): LayerNorm on load — A is the raw residual stream, each row is normalised as (x - mean) * rstd while it
-// is staged (statistics merged from the ln_tiles pairs per row the producer left; eps 1e-12); gamma must be folded into W and
-// beta into the bias by the caller.
+// ln_stats (with ln_tiles, ln_colsum): LayerNorm folded in — A is the raw residual stream x, W must be W * gamma, bias must be
+// bias + W beta and ln_colsum[n] = sum_k W[n][k] gamma[k]; the epilogue forms rstd_i * (x W'^T - mean_i * colsum) + bias with the
+// statistics merged from the ln_tiles pairs per row the producer left (eps 1e-12).
 void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile = false,
-                            const float* ln_stats = nullptr, int ln_tiles = 0, float* stats_out = nullptr, bool half_tile = false);
+                            const float* ln_stats = nullptr, int ln_tiles = 0, float* stats_out = nullptr, bool half_tile = false,
+                            const float* ln_colsum = nullptr);
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).
 bool gemm_x6_ln_ok(int M);
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
-                           float* stats_out, hipStream_t s);
+                           const float* ln_colsum, float* stats_out, hipStream_t s);
 // the same arithmetic on v_mfma_f32_16x16x32_bf16 with K-concatenated planes (gemm_x6v2.hip): 128 x 128 tile, 4 waves
 void launch_gemm_f32_bf16x6_v2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                                int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s);

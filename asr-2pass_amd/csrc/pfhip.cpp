@@ -248,29 +248,35 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     if (d == 4 * pfhip::kTileN) {   // LN-on-load needs the residual stream to be exactly four 128-column tiles wide
       // W' = W * gamma[k], b' = b + W beta: LayerNorm's affine part folded into the GEMM that consumes it (offline path,
       // large batches: enqueue_locked).  Products in double, rounded once.
-      auto fold = [&](const std::string& wn, const std::string& bn, const std::string& ln, int N, float* dw, float* db) {
+      auto fold = [&](const std::string& wn, const std::string& bn, const std::string& ln, int N, float* dw, float* db, float* ds) {
         const float* w = m->W(wn).h; const float* bb = m->W(bn).h; const float* g = m->W(ln + ".g").h; const float* be = m->W(ln + ".b").h;
         for (int n = 0; n < N; ++n) {
-          double acc = bb[n];
+          double acc = bb[n], cs = 0.0;
           for (int k = 0; k < d; ++k) {
-            dw[(size_t)n * d + k] = (float)((double)w[(size_t)n * d + k] * (double)g[k]);
+            const float wf = (float)((double)w[(size_t)n * d + k] * (double)g[k]);
+            dw[(size_t)n * d + k] = wf;
+            cs += (double)wf;                         // column sum of the weights AS STORED: what the matrix cores will multiply
             acc += (double)w[(size_t)n * d + k] * (double)be[k];
           }
           db[n] = (float)acc;
+          ds[n] = (float)cs;
         }
       };
       const int L = c.enc_layers;
       std::vector<float> wq((size_t)L * 3 * d * d + (size_t)pfhip::kTileN * d, 0.f), bq((size_t)L * 3 * d + pfhip::kTileN, 0.f);
       std::vector<float> wf((size_t)L * c.ffn * d + (size_t)pfhip::kTileN * d, 0.f), bf((size_t)L * c.ffn + pfhip::kTileN, 0.f);
+      std::vector<float> sq(bq.size(), 0.f), sf(bf.size(), 0.f);
       for (int i = 0; i < L; ++i) {
         const std::string ep = "enc." + std::to_string(i) + ".";
-        if (i > 0) fold(ep + "qkv.w", ep + "qkv.b", ep + "norm1", 3 * d, &wq[(size_t)i * 3 * d * d], &bq[(size_t)i * 3 * d]);
-        fold(ep + "ffn1.w", ep + "ffn1.b", ep + "norm2", c.ffn, &wf[(size_t)i * c.ffn * d], &bf[(size_t)i * c.ffn]);
+        if (i > 0) fold(ep + "qkv.w", ep + "qkv.b", ep + "norm1", 3 * d, &wq[(size_t)i * 3 * d * d], &bq[(size_t)i * 3 * d], &sq[(size_t)i * 3 * d]);
+        fold(ep + "ffn1.w", ep + "ffn1.b", ep + "norm2", c.ffn, &wf[(size_t)i * c.ffn * d], &bf[(size_t)i * c.ffn], &sf[(size_t)i * c.ffn]);
       }
       st = upload(&m->d_lnw_qkv, wq);
       if (!st) st = upload(&m->d_lnb_qkv, bq);
       if (!st) st = upload(&m->d_lnw_ffn1, wf);
       if (!st) st = upload(&m->d_lnb_ffn1, bf);
+      if (!st) st = upload(&m->d_lns_qkv, sq);
+      if (!st) st = upload(&m->d_lns_ffn1, sf);
       if (st) return st;
     }
     if (c.dec_layers > 0) {     // streaming latency path: all layers' K/V projections of a window in one launch (stream.cpp)
@@ -451,10 +457,10 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   const bool mem_in_x = pfhip::attention_fsmn_is_fused(m->maxT);
   if (fuse_ln) HIP_TRY(m->lnstats.ensure((size_t)Mp * 4 * 2 * 4));
   auto gemm_ln = [&](const float* A, const float* Wd, int N, float* Cd, int ldc, const float* bias, const float* R1, const float* R2,
-                     bool relu, bool ln_in, bool stats_out, int K) {
+                     bool relu, const float* ln_colsum, bool stats_out, int K) {
     Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, ldc, bias, R1, d, R2, d, M, N, K, relu, ln_in ? m->lnstats.f() : nullptr, 4,
-                                 stats_out ? m->lnstats.f() : nullptr, s);
+    pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, ldc, bias, R1, d, R2, d, M, N, K, relu, ln_colsum ? m->lnstats.f() : nullptr, 4,
+                                 ln_colsum, stats_out ? m->lnstats.f() : nullptr, s);
   };
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
@@ -463,7 +469,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
     if (fuse_ln && !first) {
       gemm_ln(x, m->d_lnw_qkv + (size_t)i * 3 * d * d, 3 * d, m->qkv.f(), 3 * d, m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, nullptr, false,
-              true, false, d);
+              m->d_lns_qkv + (size_t)i * 3 * d, false, d);
     } else {
       lnorm(m, s, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
       gemm(m, s, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
@@ -481,10 +487,10 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     // x = (first ? 0 : x) + ctx*Wo + b + fsmn_memory
     if (fuse_ln) {
       gemm_ln(m->ctx.f(), m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, mem_in_x ? x : m->mem.f(), mem_in_x || first ? nullptr : x, false,
-              false, true, d);
+              nullptr, true, d);
       gemm_ln(x, m->d_lnw_ffn1 + (size_t)i * c.ffn * d, c.ffn, m->hbuf.f(), c.ffn, m->d_lnb_ffn1 + (size_t)i * c.ffn, nullptr, nullptr, true,
-              true, false, d);
-      gemm_ln(m->hbuf.f(), m->W(p + "ffn2.w").d, d, x, d, m->W(p + "ffn2.b").d, x, nullptr, false, false, i + 1 < c.enc_layers, c.ffn);
+              m->d_lns_ffn1 + (size_t)i * c.ffn, false, d);
+      gemm_ln(m->hbuf.f(), m->W(p + "ffn2.w").d, d, x, d, m->W(p + "ffn2.b").d, x, nullptr, false, nullptr, i + 1 < c.enc_layers, c.ffn);
       continue;
     }
     gemm(m, s, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, mem_in_x ? x : m->mem.f(), d,
@@ -938,7 +944,7 @@ void pfhip_destroy(pfhip_model* m) {
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
                   (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh, (void*)m->d_kv_all_w, (void*)m->d_kv_all_b, (void*)m->d_lnw_qkv, (void*)m->d_lnb_qkv,
-                  (void*)m->d_lnw_ffn1, (void*)m->d_lnb_ffn1})
+                  (void*)m->d_lnw_ffn1, (void*)m->d_lnb_ffn1, (void*)m->d_lns_qkv, (void*)m->d_lns_ffn1})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_ops) (void)hipHostFree(m->h_ops);

@@ -130,6 +130,9 @@ struct pfhip_model {
   // bias + W beta, for qkv (layers >= 1) and ffn1; [layers][N][d] / [layers][N]
   float* d_lnw_qkv = nullptr; float* d_lnb_qkv = nullptr; float* d_lnw_ffn1 = nullptr; float* d_lnb_ffn1 = nullptr;
   float* d_lns_qkv = nullptr; float* d_lns_ffn1 = nullptr;      // column sums of the folded weights [layers][N]
+  // the same for the decoder's FFN: ffn1 with norm1, ffn2 with ffn_norm; [dec_layers + 1] entries (the last one is dec3)
+  float* d_dlnw1 = nullptr; float* d_dlnb1 = nullptr; float* d_dlns1 = nullptr;
+  float* d_dlnw2 = nullptr; float* d_dlnb2 = nullptr; float* d_dlns2 = nullptr;
   // timestamp head repacks: ConvTranspose1d as [3d][d] + tiled bias, both LSTM directions' input weights [8d][d] + summed
   // biases, recurrent weights [2][4d][d]
   float* d_up_w = nullptr; float* d_up_b = nullptr; float* d_wih = nullptr; float* d_bih = nullptr; float* d_whh = nullptr;
@@ -142,6 +145,7 @@ struct pfhip_model {
   Buf emb, xd, yd, hd, hd2, td, t2, qd, ctxd, logits, logp, ids, dmeta, cat, hw, hwkv;
   Buf sseg;                     // StreamSeg descriptors of a streaming batch
   Buf kvside;                   // [dec_layers][Mp][2d]: every decoder layer's K/V projection of the encoder output (side stream)
+  Buf lnstats2;                 // the decoder's second hand-off (FFN1 -> ffn_norm -> FFN2): [ML][dec_ffn / 128][2]
   Buf lnstats;                  // per-row LayerNorm statistics handed from a producing GEMM's epilogue to the consumer [M][4][2]
   Buf kvall;                    // one window's K/V projections of every decoder layer [32][layers * 2d]
   Buf fbk, d_ops;               // streaming batch: fbank frames of all connections, operation descriptors

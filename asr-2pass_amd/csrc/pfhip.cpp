@@ -248,19 +248,23 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     if (d == 4 * pfhip::kTileN) {   // LN-on-load needs the residual stream to be exactly four 128-column tiles wide
       // W' = W * gamma[k], b' = b + W beta: LayerNorm's affine part folded into the GEMM that consumes it (offline path,
       // large batches: enqueue_locked).  Products in double, rounded once.
-      auto fold = [&](const std::string& wn, const std::string& bn, const std::string& ln, int N, float* dw, float* db, float* ds) {
-        const float* w = m->W(wn).h; const float* bb = m->W(bn).h; const float* g = m->W(ln + ".g").h; const float* be = m->W(ln + ".b").h;
+      auto foldk = [&](const std::string& wn, const std::string& bn, const std::string& ln, int N, int K, float* dw, float* db, float* ds) {
+        const float* w = m->W(wn).h; const float* bb = bn.empty() ? nullptr : m->W(bn).h;
+        const float* g = m->W(ln + ".g").h; const float* be = m->W(ln + ".b").h;
         for (int n = 0; n < N; ++n) {
-          double acc = bb[n], cs = 0.0;
-          for (int k = 0; k < d; ++k) {
-            const float wf = (float)((double)w[(size_t)n * d + k] * (double)g[k]);
-            dw[(size_t)n * d + k] = wf;
+          double acc = bb ? bb[n] : 0.0, cs = 0.0;
+          for (int k = 0; k < K; ++k) {
+            const float wf = (float)((double)w[(size_t)n * K + k] * (double)g[k]);
+            dw[(size_t)n * K + k] = wf;
             cs += (double)wf;                         // column sum of the weights AS STORED: what the matrix cores will multiply
-            acc += (double)w[(size_t)n * d + k] * (double)be[k];
+            acc += (double)w[(size_t)n * K + k] * (double)be[k];
           }
           db[n] = (float)acc;
           ds[n] = (float)cs;
         }
+      };
+      auto fold = [&](const std::string& wn, const std::string& bn, const std::string& ln, int N, float* dw, float* db, float* ds) {
+        foldk(wn, bn, ln, N, d, dw, db, ds);
       };
       const int L = c.enc_layers;
       std::vector<float> wq((size_t)L * 3 * d * d + (size_t)pfhip::kTileN * d, 0.f), bq((size_t)L * 3 * d + pfhip::kTileN, 0.f);
@@ -277,6 +281,22 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
       if (!st) st = upload(&m->d_lnb_ffn1, bf);
       if (!st) st = upload(&m->d_lns_qkv, sq);
       if (!st) st = upload(&m->d_lns_ffn1, sf);
+      if (!st && c.dec_ffn % pfhip::kTileN == 0) {          // decoder FFNs: layers 0..dec_layers-1 and dec3 (the last entry)
+        const int DL = c.dec_layers + 1, f = c.dec_ffn;
+        std::vector<float> w1((size_t)DL * f * d + (size_t)pfhip::kTileN * d, 0.f), b1((size_t)DL * f + pfhip::kTileN, 0.f), s1(b1.size(), 0.f);
+        std::vector<float> w2((size_t)DL * d * f + (size_t)pfhip::kTileN * f, 0.f), b2((size_t)DL * d + pfhip::kTileN, 0.f), s2(b2.size(), 0.f);
+        for (int i = 0; i < DL; ++i) {
+          const std::string dp = i < c.dec_layers ? "dec." + std::to_string(i) + "." : std::string("dec3.");
+          foldk(dp + "ffn1.w", dp + "ffn1.b", dp + "norm1", f, d, &w1[(size_t)i * f * d], &b1[(size_t)i * f], &s1[(size_t)i * f]);
+          foldk(dp + "ffn2.w", "", dp + "ffn_norm", d, f, &w2[(size_t)i * d * f], &b2[(size_t)i * d], &s2[(size_t)i * d]);
+        }
+        st = upload(&m->d_dlnw1, w1);
+        if (!st) st = upload(&m->d_dlnb1, b1);
+        if (!st) st = upload(&m->d_dlns1, s1);
+        if (!st) st = upload(&m->d_dlnw2, w2);
+        if (!st) st = upload(&m->d_dlnb2, b2);
+        if (!st) st = upload(&m->d_dlns2, s2);
+      }
       if (st) return st;
     }
     if (c.dec_layers > 0) {     // streaming latency path: all layers' K/V projections of a window in one launch (stream.cpp)
@@ -597,7 +617,35 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   }
   double cross_pairs = 0;
   for (int b = 0; b < B; ++b) cross_pairs += (double)m->n_fires[b] * m->T[b];
-  auto dec_ffn = [&](const std::string& p, const float* xin, float* out) {
+  // The decoder's FFN LayerNorms fold the same way (rows >= 4096): norm1 into FFN1 — its input is the residual stream the
+  // previous layer's output projection wrote (statistics from that epilogue; the first layer's input comes from the CIF, so it
+  // keeps its LayerNorm launch) — and the 2048-wide ffn_norm into FFN2 (FFN1's epilogue leaves 16 pairs per row, after its ReLU).
+  const bool fuse_dec = m->d_dlnw1 != nullptr && pfhip::gemm_x6_ln_ok(ML);
+  const int ftiles = c.dec_ffn / pfhip::kTileN;
+  if (fuse_dec) {
+    HIP_TRY(m->lnstats.ensure((size_t)std::max(Mp, MLp) * 4 * 2 * 4));
+    HIP_TRY(m->lnstats2.ensure((size_t)MLp * ftiles * 2 * 4));
+  }
+  auto x6ln = [&](const float* A, int K, const float* Wd, int N, float* Cd, const float* bias, const float* R1, bool relu,
+                  const float* st_in, int tiles_in, const float* colsum, float* st_out) {
+    Scope sc(m, s, K_GEMM, 2.0 * ML * (double)N * K, 4.0 * ((double)ML * K + (double)N * K + (double)ML * N));
+    pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, N, bias, R1, d, nullptr, 0, ML, N, K, relu, st_in, tiles_in, colsum, st_out, s);
+  };
+  bool xd_has_stats = false;          // lnstats holds the row statistics of the current xd
+  auto dec_ffn = [&](const std::string& p, int li, const float* xin, float* out) {
+    if (fuse_dec) {
+      if (xd_has_stats) {
+        x6ln(xin, d, m->d_dlnw1 + (size_t)li * c.dec_ffn * d, c.dec_ffn, m->hd.f(), m->d_dlnb1 + (size_t)li * c.dec_ffn, nullptr, true,
+             m->lnstats.f(), 4, m->d_dlns1 + (size_t)li * c.dec_ffn, m->lnstats2.f());
+      } else {
+        lnorm(m, s, xin, d, m->yd.f(), d, p + "norm1", ML, d, d);
+        x6ln(m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, m->hd.f(), m->W(p + "ffn1.b").d, nullptr, true, nullptr, 0, nullptr,
+             m->lnstats2.f());
+      }
+      x6ln(m->hd.f(), c.dec_ffn, m->d_dlnw2 + (size_t)li * d * c.dec_ffn, d, out, m->d_dlnb2 + (size_t)li * d, nullptr, false, m->lnstats2.f(),
+           ftiles, m->d_dlns2 + (size_t)li * d, nullptr);
+      return;
+    }
     lnorm(m, s, xin, d, m->yd.f(), d, p + "norm1", ML, d, d);
     gemm(m, s, m->yd.f(), d, m->W(p + "ffn1.w").d, c.dec_ffn, d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr,
          0, nullptr, 0, ML, true);
@@ -607,7 +655,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   };
   for (int i = 0; i < c.dec_layers; ++i) {
     const std::string p = "dec." + std::to_string(i) + ".";
-    dec_ffn(p, xd, m->td.f());
+    dec_ffn(p, i, xd, m->td.f());
     lnorm(m, s, m->td.f(), d, m->t2.f(), d, p + "norm2", ML, d, d);
     {
       Scope sc(m, s, K_FSMN, 2.0 * 11 * ML * d, 12.0 * ML * d);
@@ -627,8 +675,14 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
       pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
                               m->m_row_off, m->m_len, B, c.n_head, m->maxL, att_scale, s);
     }
+    xd_has_stats = false;
     if (!(c.contextual && i == c.dec_layers - 1)) {
-      gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
+      if (fuse_dec) {          // the output projection also leaves the statistics the next norm1 needs
+        x6ln(m->ctxd.f(), d, m->W(p + "out.w").d, d, xd, m->W(p + "out.b").d, xd, false, nullptr, 0, nullptr, m->lnstats.f());
+        xd_has_stats = true;
+      } else {
+        gemm(m, s, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
+      }
       continue;
     }
     // ---- contextual last layer (UPSTREAM ContextualDecoderLayer + ContextualBiasDecoder + bias_output):
@@ -651,7 +705,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
          0, ML, false);
     gemm(m, s, cat, 2 * d, m->W("bias.out.w").d, d, 2 * d, 2 * d, xd, d, nullptr, xd, d, nullptr, 0, ML, false);
   }
-  dec_ffn("dec3.", xd, m->td.f());
+  dec_ffn("dec3.", c.dec_layers, xd, m->td.f());
   lnorm(m, s, m->td.f(), d, m->yd.f(), d, "dec.after_norm", ML, d, d);
   gemm(m, s, m->yd.f(), d, m->W("dec.out.w").d, c.vocab, d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
        nullptr, 0, ML, false);
@@ -939,12 +993,13 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->kvside, &m->ts_cst})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst})
     b->release();
   for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
                   (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh, (void*)m->d_kv_all_w, (void*)m->d_kv_all_b, (void*)m->d_lnw_qkv, (void*)m->d_lnb_qkv,
-                  (void*)m->d_lnw_ffn1, (void*)m->d_lnb_ffn1, (void*)m->d_lns_qkv, (void*)m->d_lns_ffn1})
+                  (void*)m->d_lnw_ffn1, (void*)m->d_lnb_ffn1, (void*)m->d_lns_qkv, (void*)m->d_lns_ffn1, (void*)m->d_dlnw1, (void*)m->d_dlnb1, (void*)m->d_dlns1,
+                  (void*)m->d_dlnw2, (void*)m->d_dlnb2, (void*)m->d_dlns2})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_ops) (void)hipHostFree(m->h_ops);

@@ -16,7 +16,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpfhip.so")
+# PFHIP_LIB: another build of the same library (A/B timing of two builds inside one GPU session; tools/ab_bench.sh)
+LIB_PATH = os.environ.get("PFHIP_LIB") or os.path.join(_HERE, "libpfhip.so")
 
 PFHIP_NUM_KCLASS = 8
 KCLASS_NAMES = ["gemm", "attention", "layernorm", "fsmn", "fbank", "cif", "head", "other"]

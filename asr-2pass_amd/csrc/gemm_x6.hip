@@ -217,12 +217,21 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
 #undef PFHIP_SGB
 #undef PFHIP_X6
 #undef PFHIP_FRAGS
+  // residual rows of the whole tile requested before the accumulators go through LDS: one memory latency for the epilogue
+  // instead of one per pass
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 r1v[16];
+#pragma unroll
+  for (int pass = 0; pass < 16; ++pass) {
+    const int grow = m0 + pass * 16 + rsub;
+    r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();                        // every wave has finished reading operand fragments
 
   // ---- epilogue: two 128-row halves through LDS (C/D map: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)) ------------------
   float* const Cs = reinterpret_cast<float*>(lds);
-  const int c4 = tid & 31, rsub = tid >> 5;
-  const int gcol = n0 + 4 * c4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) {
     if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
       if (gcol + 2 < N) bv.z = bias[gcol + 2];
     }
   }
-#pragma unroll 1
+#pragma unroll
   for (int half = 0; half < 2; ++half) {
     if ((wr >> 1) == half) {
       float* cw = Cs + ((wr & 1) * 64 + 4 * h) * kCs + wc * 64 + r;
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
       }
     }
     __syncthreads();
-#pragma unroll 2
+#pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
       const int row = pass * 16 + rsub;
       const int grow = m0 + half * 128 + row;
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(
       v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       if (grow < M && gcol + 3 < N) {
         if (R1) {
-          const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+          const float4 t = r1v[half * 8 + pass];
           v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         if (R2) {
@@ -391,6 +400,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
 #undef PFHIP_SGB
 #undef PFHIP_X6
 #undef PFHIP_FRAGS
+  // residual rows of the whole tile requested before the accumulators go through LDS: one memory latency for the epilogue
+  // instead of one per pass
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 r1v[8];
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int grow = m0 + pass * 16 + rsub;
+    r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
 
   float* const Cs = reinterpret_cast<float*>(lds);
@@ -407,8 +427,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
   static_assert(kSM * kCs * 4 + kSM * 8 <= kSLdsBytes, "row statistics must fit behind the C tile");
   if (LN && tid < kSM) s_mr[tid] = ln_mr;
   __syncthreads();
-  const int c4 = tid & 31, rsub = tid >> 5;
-  const int gcol = n0 + 4 * c4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) {
     if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
   }
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
-#pragma unroll 2
+#pragma unroll
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 16 + rsub;
     const int grow = m0 + row;
@@ -429,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_128_kernel(
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     if (grow < M && gcol + 3 < N) {
       if (R1) {
-        const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+        const float4 t = r1v[pass];
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
       if (R2) {
@@ -552,6 +570,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
 #undef PFHIP_LOAD_RAW
 #undef PFHIP_X6
 #undef PFHIP_FRAGS
+  // residual rows of the whole tile requested before the accumulators go through LDS: one memory latency for the epilogue
+  // instead of one per pass
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const int gcol = n0 + 4 * c4;
+  float4 r1v[4];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int grow = m0 + pass * 16 + rsub;
+    r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
 
   float* const Cs = reinterpret_cast<float*>(lds);
@@ -564,8 +593,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
   static_assert(kHM * kCs * 4 + kHM * 8 <= kHLdsBytes, "row statistics must fit behind the C tile");
   if (LN && tid < kHM) s_mr[tid] = ln_mr;
   __syncthreads();
-  const int c4 = tid & 31, rsub = tid >> 5;
-  const int gcol = n0 + 4 * c4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) {
     if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
   }
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
-#pragma unroll 2
+#pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int row = pass * 16 + rsub;
     const int grow = m0 + row;
@@ -586,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_bf16x6_64_kernel(
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     if (grow < M && gcol + 3 < N) {
       if (R1) {
-        const float4 t = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol);
+        const float4 t = r1v[pass];
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
       if (R2) {

@@ -133,6 +133,7 @@ struct pfhip_model {
   // the same for the decoder's FFN: ffn1 with norm1, ffn2 with ffn_norm; [dec_layers + 1] entries (the last one is dec3)
   float* d_dlnw1 = nullptr; float* d_dlnb1 = nullptr; float* d_dlns1 = nullptr;
   float* d_dlnw2 = nullptr; float* d_dlnb2 = nullptr; float* d_dlns2 = nullptr;
+  float* d_dlnw3 = nullptr; float* d_dlnb3 = nullptr; float* d_dlns3 = nullptr;     // norm3 -> q projection (streaming latency path)
   // timestamp head repacks: ConvTranspose1d as [3d][d] + tiled bias, both LSTM directions' input weights [8d][d] + summed
   // biases, recurrent weights [2][4d][d]
   float* d_up_w = nullptr; float* d_up_b = nullptr; float* d_wih = nullptr; float* d_bih = nullptr; float* d_whh = nullptr;

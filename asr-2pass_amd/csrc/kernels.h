@@ -207,6 +207,11 @@ void launch_fsmn_cached(const float* t2, const float* w, const float* res, float
 void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const float* b, float eps, const float* W, int ldw,
                           float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
                           const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, bool relu, hipStream_t s);
+// the same operator with every operand requested in one trip and LayerNorm applied algebraically (stream_fused.hip): W / bias are
+// the gamma/beta-folded ones and ln_colsum their column sums when the LayerNorm is wanted.  Returns false for shapes it does not take.
+bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, float* C, int ldc, const float* bias, const float* ln_colsum,
+                             float eps, const float* R1, int ldr1, const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K,
+                             bool relu, hipStream_t s);
 
 // ---- FSMN-VAD pieces --------------------------------------------------------------
 // Generic LfrCmvn over raw fbank frames fb [F, n_mels] -> out [T = ceil(F/n), ldo] (columns >= m*n_mels zeroed).

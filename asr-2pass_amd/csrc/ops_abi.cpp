@@ -41,6 +41,23 @@ int pfhip_dev_fused_ln_gemm_bench(const float* X, int ldx, int D, const float* g
                                 0, nullptr, 0, nullptr, M, N, K, relu != 0, S(stream));
   return done();
 }
+int pfhip_op_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, float* C, int ldc, const float* bias,
+                              const float* ln_colsum, float eps, const float* R1, int ldr1, const float* fsmn_v, int ldv,
+                              const float* fsmn_w, int M, int N, int K, int relu, void* stream) {
+  if (!pfhip::launch_fused_gemv_1trip(X, ldx, W, ldw, C, ldc, bias, ln_colsum, eps, R1, ldr1, fsmn_v, ldv, fsmn_w, M, N, K, relu != 0, S(stream)))
+    return (int)hipErrorInvalidValue;
+  return done();
+}
+// dev hook (tools/fused_gemv_bench.py): the one-trip form over the same ring of weight copies
+int pfhip_dev_fused_gemv_1trip_bench(const float* X, int ldx, const float* W, int ldw, size_t w_stride_floats, int n_copies, float* C, int ldc,
+                                     const float* bias, const float* ln_colsum, const float* R1, int ldr1, int M, int N, int K, int relu,
+                                     int n_launch, void* stream) {
+  for (int i = 0; i < n_launch; ++i)
+    if (!pfhip::launch_fused_gemv_1trip(X, ldx, W + (size_t)(i % n_copies) * w_stride_floats, ldw, C, ldc, bias, ln_colsum, 1e-12f, R1, ldr1,
+                                        nullptr, 0, nullptr, M, N, K, relu != 0, S(stream)))
+      return (int)hipErrorInvalidValue;
+  return done();
+}
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream) {
   if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;

@@ -285,11 +285,17 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
         const int DL = c.dec_layers + 1, f = c.dec_ffn;
         std::vector<float> w1((size_t)DL * f * d + (size_t)pfhip::kTileN * d, 0.f), b1((size_t)DL * f + pfhip::kTileN, 0.f), s1(b1.size(), 0.f);
         std::vector<float> w2((size_t)DL * d * f + (size_t)pfhip::kTileN * f, 0.f), b2((size_t)DL * d + pfhip::kTileN, 0.f), s2(b2.size(), 0.f);
+        std::vector<float> w3((size_t)DL * d * d + (size_t)pfhip::kTileN * d, 0.f), b3((size_t)DL * d + pfhip::kTileN, 0.f), s3(b3.size(), 0.f);
         for (int i = 0; i < DL; ++i) {
           const std::string dp = i < c.dec_layers ? "dec." + std::to_string(i) + "." : std::string("dec3.");
           foldk(dp + "ffn1.w", dp + "ffn1.b", dp + "norm1", f, d, &w1[(size_t)i * f * d], &b1[(size_t)i * f], &s1[(size_t)i * f]);
           foldk(dp + "ffn2.w", "", dp + "ffn_norm", d, f, &w2[(size_t)i * d * f], &b2[(size_t)i * d], &s2[(size_t)i * d]);
+          if (i < c.dec_layers) foldk(dp + "q.w", dp + "q.b", dp + "norm3", d, d, &w3[(size_t)i * d * d], &b3[(size_t)i * d], &s3[(size_t)i * d]);
         }
+        st = upload(&m->d_dlnw3, w3);
+        if (!st) st = upload(&m->d_dlnb3, b3);
+        if (!st) st = upload(&m->d_dlns3, s3);
+        if (st) return st;
         st = upload(&m->d_dlnw1, w1);
         if (!st) st = upload(&m->d_dlnb1, b1);
         if (!st) st = upload(&m->d_dlns1, s1);
@@ -999,7 +1005,7 @@ void pfhip_destroy(pfhip_model* m) {
                   (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
                   (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh, (void*)m->d_kv_all_w, (void*)m->d_kv_all_b, (void*)m->d_lnw_qkv, (void*)m->d_lnb_qkv,
                   (void*)m->d_lnw_ffn1, (void*)m->d_lnb_ffn1, (void*)m->d_lns_qkv, (void*)m->d_lns_ffn1, (void*)m->d_dlnw1, (void*)m->d_dlnb1, (void*)m->d_dlns1,
-                  (void*)m->d_dlnw2, (void*)m->d_dlnb2, (void*)m->d_dlns2})
+                  (void*)m->d_dlnw2, (void*)m->d_dlnb2, (void*)m->d_dlns2, (void*)m->d_dlnw3, (void*)m->d_dlnb3, (void*)m->d_dlns3})
     if (p) (void)hipFree(p);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_ops) (void)hipHostFree(m->h_ops);

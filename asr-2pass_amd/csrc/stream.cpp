@@ -271,6 +271,12 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     pfhip::launch_fused_ln_gemm(X, ldx, D, norm.empty() ? nullptr : m->W(norm + ".g").d, norm.empty() ? nullptr : m->W(norm + ".b").d,
                                 1e-12f, Wd, ldw, Cd, ldc, bias, R1, ldr1, R2, ldr2, fv, ldv, fw, rows, N, K, relu, st);
   };
+  // one-trip form of the same launches where the shape allows (stream_fused.hip: every operand requested at once, LayerNorm
+  // applied algebraically on the gamma/beta-folded weights built at load); false -> the caller uses ln_gemm
+  auto gemv1 = [&](const float* X, int ldx, const float* Wd, int ldw, float* Cd, int ldc, const float* bias, const float* colsum,
+                   const float* R1, int ldr1, const float* fv, int ldv, const float* fw, int rows, int N, int K, bool relu) {
+    return Wd && pfhip::launch_fused_gemv_1trip(X, ldx, Wd, ldw, Cd, ldc, bias, colsum, 1e-12f, R1, ldr1, fv, ldv, fw, rows, N, K, relu, st);
+  };
   // ---- streaming encoder session (:448): SAN-M stack on the windows as given (no scale/PE inside) --------
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
@@ -279,16 +285,26 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
     if (lean) {
       // 5 launches: LN1+QKV | attention | out-projection + FSMN memory + residual | LN2+FFN1 | FFN2 + residual
-      ln_gemm(xin, ldin, Din, p + "norm1", first ? m->d_w0qkv : m->W(p + "qkv.w").d, Kp, m->qkv.f(), 3 * d, m->W(p + "qkv.b").d,
-              nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, Kp, false);
+      if (first || !m->d_lnw_qkv ||
+          !gemv1(x, d, m->d_lnw_qkv + (size_t)i * 3 * d * d, d, m->qkv.f(), 3 * d, m->d_lnb_qkv + (size_t)i * 3 * d,
+                 m->d_lns_qkv + (size_t)i * 3 * d, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, d, false))
+        ln_gemm(xin, ldin, Din, p + "norm1", first ? m->d_w0qkv : m->W(p + "qkv.w").d, Kp, m->qkv.f(), 3 * d, m->W(p + "qkv.b").d,
+                nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, Kp, false);
       pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
                               d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
-      ln_gemm(m->ctx.f(), d, 0, "", m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, nullptr, 0,
-              m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, M, d, d, false);
-      ln_gemm(x, d, d, p + "norm2", m->W(p + "ffn1.w").d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0, nullptr, 0,
-              nullptr, 0, nullptr, M, c.ffn, d, true);
-      ln_gemm(m->hbuf.f(), c.ffn, 0, "", m->W(p + "ffn2.w").d, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0, nullptr, 0,
-              nullptr, M, d, c.ffn, false);
+      if (!gemv1(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, nullptr, first ? nullptr : x, d, m->qkv.f() + 2 * d,
+                 3 * d, m->W(p + "fsmn.w").d, M, d, d, false))
+        ln_gemm(m->ctx.f(), d, 0, "", m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, nullptr, 0,
+                m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, M, d, d, false);
+      if (!m->d_lnw_ffn1 ||
+          !gemv1(x, d, m->d_lnw_ffn1 + (size_t)i * c.ffn * d, d, m->hbuf.f(), c.ffn, m->d_lnb_ffn1 + (size_t)i * c.ffn,
+                 m->d_lns_ffn1 + (size_t)i * c.ffn, nullptr, 0, nullptr, 0, nullptr, M, c.ffn, d, true))
+        ln_gemm(x, d, d, p + "norm2", m->W(p + "ffn1.w").d, d, m->hbuf.f(), c.ffn, m->W(p + "ffn1.b").d, nullptr, 0, nullptr, 0,
+                nullptr, 0, nullptr, M, c.ffn, d, true);
+      if (!gemv1(m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, c.ffn, x, d, m->W(p + "ffn2.b").d, nullptr, x, d, nullptr, 0, nullptr, M, d,
+                 c.ffn, false))
+        ln_gemm(m->hbuf.f(), c.ffn, 0, "", m->W(p + "ffn2.w").d, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0, nullptr, 0,
+                nullptr, M, d, c.ffn, false);
       continue;
     }
     lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
@@ -372,12 +388,17 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   float* kvbuf = m->qkv.f();
   pfhip::launch_compact(m->emb.f(), xd, d_src_row, ML, d, st);
   const bool lean_dec = lean && ML <= 32;
-  auto dec_ffn = [&](const std::string& p, const float* xin, float* o) {
+  auto dec_ffn = [&](const std::string& p, int li, const float* xin, float* o) {
     if (lean_dec) {          // LN1+FFN1 | ffn_norm+FFN2
-      ln_gemm(xin, d, d, p + "norm1", m->W(p + "ffn1.w").d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr, 0, nullptr, 0,
-              nullptr, 0, nullptr, ML, c.dec_ffn, d, true);
-      ln_gemm(m->hd.f(), c.dec_ffn, c.dec_ffn, p + "ffn_norm", m->W(p + "ffn2.w").d, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
-              nullptr, 0, nullptr, ML, d, c.dec_ffn, false);
+      const int f = c.dec_ffn;
+      if (!m->d_dlnw1 || !gemv1(xin, d, m->d_dlnw1 + (size_t)li * f * d, d, m->hd.f(), f, m->d_dlnb1 + (size_t)li * f,
+                                m->d_dlns1 + (size_t)li * f, nullptr, 0, nullptr, 0, nullptr, ML, f, d, true))
+        ln_gemm(xin, d, d, p + "norm1", m->W(p + "ffn1.w").d, d, m->hd.f(), c.dec_ffn, m->W(p + "ffn1.b").d, nullptr, 0, nullptr, 0,
+                nullptr, 0, nullptr, ML, c.dec_ffn, d, true);
+      if (!m->d_dlnw2 || !gemv1(m->hd.f(), f, m->d_dlnw2 + (size_t)li * d * f, f, o, d, m->d_dlnb2 + (size_t)li * d,
+                                m->d_dlns2 + (size_t)li * d, nullptr, 0, nullptr, 0, nullptr, ML, d, f, false))
+        ln_gemm(m->hd.f(), c.dec_ffn, c.dec_ffn, p + "ffn_norm", m->W(p + "ffn2.w").d, c.dec_ffn, o, d, nullptr, nullptr, 0, nullptr, 0,
+                nullptr, 0, nullptr, ML, d, c.dec_ffn, false);
       return;
     }
     lnorm(m, st, xin, d, m->yd.f(), d, p + "norm1", ML, d, d);
@@ -390,22 +411,27 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   const int kv_ld = c.dec_layers * 2 * d;
   if (lean_dec) {            // the window is the same for every layer: all K/V projections in one launch
     HIP_TRY(m->kvall.ensure((size_t)32 * (kv_ld + pfhip::kTileN) * 4));
-    ln_gemm(m->enc.f(), d, 0, "", m->d_kv_all_w, d, m->kvall.f(), kv_ld, m->d_kv_all_b, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M,
-            kv_ld, d, false);
+    if (!gemv1(m->enc.f(), d, m->d_kv_all_w, d, m->kvall.f(), kv_ld, m->d_kv_all_b, nullptr, nullptr, 0, nullptr, 0, nullptr, M, kv_ld, d,
+               false))
+      ln_gemm(m->enc.f(), d, 0, "", m->d_kv_all_w, d, m->kvall.f(), kv_ld, m->d_kv_all_b, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M,
+              kv_ld, d, false);
   }
   for (int i = 0; i < c.dec_layers; ++i) {
     const std::string p = "dec." + std::to_string(i) + ".";
-    dec_ffn(p, xd, m->td.f());
+    dec_ffn(p, i, xd, m->td.f());
     lnorm(m, st, m->td.f(), d, m->t2.f(), d, p + "norm2", ML, d, d);
     pfhip::launch_fsmn_cached(m->t2.f(), m->W(p + "fsmn.w").d, xd, xd, d_segs, B, i, d, st);
     if (lean_dec) {
-      ln_gemm(xd, d, d, p + "norm3", m->W(p + "q.w").d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, nullptr, 0,
-              nullptr, ML, d, d, false);
+      if (!m->d_dlnw3 || !gemv1(xd, d, m->d_dlnw3 + (size_t)i * d * d, d, m->qd.f(), d, m->d_dlnb3 + (size_t)i * d,
+                                m->d_dlns3 + (size_t)i * d, nullptr, 0, nullptr, 0, nullptr, ML, d, d, false))
+        ln_gemm(xd, d, d, p + "norm3", m->W(p + "q.w").d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, nullptr, 0,
+                nullptr, ML, d, d, false);
       const float* kvl = m->kvall.f() + (size_t)i * 2 * d;
       pfhip::launch_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
                               c.n_head, maxN, att_scale, st);
-      ln_gemm(m->ctxd.f(), d, 0, "", m->W(p + "out.w").d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, nullptr, 0, nullptr,
-              ML, d, d, false);
+      if (!gemv1(m->ctxd.f(), d, m->W(p + "out.w").d, d, xd, d, m->W(p + "out.b").d, nullptr, xd, d, nullptr, 0, nullptr, ML, d, d, false))
+        ln_gemm(m->ctxd.f(), d, 0, "", m->W(p + "out.w").d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, nullptr, 0, nullptr,
+                ML, d, d, false);
       continue;
     }
     lnorm(m, st, xd, d, m->yd.f(), d, p + "norm3", ML, d, d);
@@ -416,7 +442,7 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
                             c.n_head, maxN, att_scale, st);
     gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
   }
-  dec_ffn("dec3.", xd, m->td.f());
+  dec_ffn("dec3.", c.dec_layers, xd, m->td.f());
   if (lean_dec) {
     ln_gemm(m->td.f(), d, d, "dec.after_norm", m->W("dec.out.w").d, d, m->logits.f(), m->vocab_pad, m->d_vocab_bias, nullptr, 0,
             nullptr, 0, nullptr, 0, nullptr, ML, c.vocab, d, false);

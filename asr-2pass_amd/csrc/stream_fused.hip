@@ -300,6 +300,135 @@ __global__ __launch_bounds__(1024) void fused_ln_gemv_kernel(
   C[(size_t)row * ldc + gcol] = v;
 }
 
+
+// ---- second form: ONE trip to memory ------------------------------------------------------------------------------------------
+// What the kernel above still waits for is not bytes but dependent round trips: row statistics (one), then the activation rows in
+// three groups of eight (three), then the epilogue's operands (one); and 60-180 cross-lane shuffles per wave.  Here
+//   * lane = (output column c of CW, row group rg of RG, k-subset ks of KS), CW * RG * KS = 64: a lane owns RPL rows and NF float4s
+//     of k, a wave owns ONE k-block (K = KS * 4 NF * waves: every launch shape of a window), so a lane's whole input — NF weight
+//     float4s and RPL x NF activation float4s — is requested at once, and so are bias / residual / column sums by the lanes that
+//     will finish the outputs; splitting the rows over lanes instead of the k range leaves log2(KS) = 1-3 shuffle steps on RPL values;
+//   * LayerNorm is applied algebraically, as in the offline GEMMs (gemm_x6.hip): with gamma folded into the weights at load
+//     (W' = W gamma, b' = b + W beta, s_n = sum_k W'_nk)      LN(x) W^T = rstd_i * (x W'^T - mean_i * s_n) + b'_n,
+//     and mean_i / rstd_i come out of the SAME loaded values: every lane forms (mean, M2) of its 4 NF elements of a row (two passes
+//     over registers), the k-subsets of a wave and then the waves are merged with Chan's formula (equal counts) next to the dot
+//     products — as accurate as the two-pass form, no second pass over x.
+template <bool LN, bool FS, int CW, int CPL, int RG, int RPL, int NF>
+__global__ __launch_bounds__(1024) void fused_gemv1t_kernel(
+    const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, float* C, int ldc, const float* __restrict__ bias,
+    const float* __restrict__ colsum, float eps, const float* R1, int ldr1, const float* __restrict__ V, int ldv,
+    const float* __restrict__ fw, int M, int N, int K, int relu) {
+  constexpr int CG = CW / CPL;           // column groups: a lane owns CPL adjacent output columns
+  constexpr int KS = 64 / (CG * RG);     // k-subsets per wave
+  constexpr int KL = 4 * NF;             // k per lane
+  constexpr int KI = KS * KL;            // k per wave
+  constexpr int MR = RG * RPL;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  __shared__ float red[kWaves][MR * CW];
+  __shared__ float2 st[kWaves][MR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const int cg = lane % CG, rg = (lane / CG) % RG, ks = lane / (CG * RG);
+  const int n0 = blockIdx.x * CW;
+  const int k = wave * KI + ks * KL;
+  // everything this lane will ever read, in flight together
+  f32x4 w[CPL][NF], a[RPL][NF];
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)         // weights are read once per window: non-temporal
+      w[cc][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)(n0 + cg * CPL + cc) * ldw + k + 4 * j));
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    const int row = rg * RPL + i;
+    const float* xr = X + (size_t)(row < M ? row : M - 1) * ldx + k;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) a[i][j] = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+  }
+  const int erow = tid / CW, ecol = tid % CW, gcol = n0 + ecol;
+  const bool fin = tid < MR * CW && erow < M && gcol < N;
+  float e_bias = 0.f, e_cs = 0.f, e_r1 = 0.f;
+  if (fin) {
+    if (bias) e_bias = bias[gcol];
+    if (LN) e_cs = colsum[gcol];
+    if (R1) e_r1 = R1[(size_t)erow * ldr1 + gcol];
+  }
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    float d[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) {
+      d[cc] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        d[cc] = fmaf(a[i][j][0], w[cc][j][0], d[cc]); d[cc] = fmaf(a[i][j][1], w[cc][j][1], d[cc]);
+        d[cc] = fmaf(a[i][j][2], w[cc][j][2], d[cc]); d[cc] = fmaf(a[i][j][3], w[cc][j][3], d[cc]);
+      }
+    }
+    float mu = 0.f, q = 0.f;
+    if (LN) {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) mu += (a[i][j][0] + a[i][j][1]) + (a[i][j][2] + a[i][j][3]);
+      mu *= 1.0f / (float)KL;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const float d0 = a[i][j][0] - mu, d1 = a[i][j][1] - mu, d2 = a[i][j][2] - mu, d3 = a[i][j][3] - mu;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    }
+    float half_n = 0.5f * (float)KL;     // half the element count of each side of a merge
+#pragma unroll
+    for (int o = CG * RG; o < 64; o <<= 1) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) d[cc] += __shfl_xor(d[cc], o);
+      if (LN) {
+        const float mo = __shfl_xor(mu, o), qo = __shfl_xor(q, o);
+        const float dm = mo - mu;
+        q = (q + qo) + dm * dm * half_n;
+        mu = 0.5f * (mu + mo);
+        half_n *= 2.0f;
+      }
+    }
+    if (ks == 0) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) red[wave][(rg * RPL + i) * CW + cg * CPL + cc] = d[cc];
+    }
+    if (LN && ks == 0 && cg == 0) st[wave][rg * RPL + i] = make_float2(mu, q);
+  }
+  // the FSMN memory's operands (output projection of the encoder): requested before the barrier, consumed after it
+  float fv[11], fk[11];
+  if (FS) {
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int t = erow + j - 5;
+      const bool in = fin && t >= 0 && t < M;
+      fv[j] = in ? V[(size_t)t * ldv + gcol] : 0.f;
+      fk[j] = fin ? fw[gcol * 11 + j] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (!fin) return;
+  float v = 0.f;
+  for (int w2 = 0; w2 < n_waves; ++w2) v += red[w2][tid];
+  if (LN) {
+    float msum = 0.f, m2 = 0.f;
+    for (int w2 = 0; w2 < n_waves; ++w2) msum += st[w2][erow].x;
+    const float mean = msum / (float)n_waves;
+    for (int w2 = 0; w2 < n_waves; ++w2) { const float dm = st[w2][erow].x - mean; m2 += st[w2][erow].y + (float)KI * dm * dm; }
+    const float rstd = 1.0f / sqrtf(m2 / (float)K + eps);
+    v = rstd * (v - mean * e_cs);
+  }
+  v += e_bias;
+  v += e_r1;
+  if (FS) {
+    float mem = fv[5];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) mem += fk[j] * fv[j];
+    v += mem;
+  }
+  if (relu) v = fmaxf(v, 0.f);
+  C[(size_t)erow * ldc + gcol] = v;
+}
+
 }  // namespace
 
 template <bool LN, int CW>
@@ -351,6 +480,47 @@ void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const 
     if (cwm == 4) PFHIP_LAUNCH(false, 4); else if (cwm == 8) PFHIP_LAUNCH(false, 8); else PFHIP_LAUNCH(false, 32);
   }
 #undef PFHIP_LAUNCH
+}
+
+
+// One-trip form (fused_gemv1t_kernel).  W / bias are the LayerNorm-folded ones when ln_colsum is given (the caller's LayerNorm is
+// over exactly the K operand columns).  False when the shape is outside what the kernel takes — the caller falls back to
+// launch_fused_ln_gemm with the plain weights.  PFHIP_STREAM_1TRIP=0 turns it off.
+bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, float* C, int ldc, const float* bias, const float* ln_colsum,
+                             float eps, const float* R1, int ldr1, const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K,
+                             bool relu, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("PFHIP_STREAM_1TRIP"); return !(e && e[0] == '0'); }();
+  if (!on || M <= 0 || M > 20 || N <= 0 || (fsmn_v && ln_colsum)) return false;
+  // patch width as in launch_fused_ln_gemm; rows over 4 lane groups; a wave per k-block: K = waves * KS * 4 NF
+  static const int cpl = [] { const char* e = getenv("PFHIP_1T_CPL"); return e ? atoi(e) : 2; }();     // columns per lane (measured: 2 beats 1 and 4 on every window shape)
+  const int cw = N <= 640 ? (K >= 2048 ? 2 : 4) : 8;
+  if (cpl > cw || (cpl != 1 && cpl != 2 && cpl != 4)) return false;
+  const int ks = 64 / (cw / cpl * 4);
+  const int nf = K / (kWaves * ks * 4) >= 1 ? K / (kWaves * ks * 4) : 1;
+  const int ki = ks * 4 * nf;
+  if (K % ki || K / ki > kWaves || N % cw || (nf != 1 && nf != 2 && nf != 4)) return false;
+  const dim3 grid(N / cw), block(64 * (K / ki));
+#define PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, RPL_, NF_)                                                                                      \
+  hipLaunchKernelGGL((fused_gemv1t_kernel<LN_, FS_, CW_, CPL_, 4, RPL_, NF_>), grid, block, 0, s, X, ldx, W, ldw, C, ldc, bias, ln_colsum, eps, \
+                     R1, ldr1, fsmn_v, ldv, fsmn_w, M, N, K, relu ? 1 : 0)
+#define PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, NF_)                                   \
+  do { if (M <= 8) PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, 2, NF_); else PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, 5, NF_); } while (0)
+#define PFHIP_PICK_NF(LN_, FS_, CW_, CPL_)                                        \
+  do { if (nf == 1) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 1); else if (nf == 2) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 2); else PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 4); } while (0)
+#define PFHIP_PICK_CW(LN_, FS_)                                                                       \
+  do {                                                                                                \
+    if (cpl == 1) { if (cw == 2) PFHIP_PICK_NF(LN_, FS_, 2, 1); else if (cw == 4) PFHIP_PICK_NF(LN_, FS_, 4, 1); else PFHIP_PICK_NF(LN_, FS_, 8, 1); } \
+    else if (cpl == 2) { if (cw == 2) PFHIP_PICK_NF(LN_, FS_, 2, 2); else if (cw == 4) PFHIP_PICK_NF(LN_, FS_, 4, 2); else PFHIP_PICK_NF(LN_, FS_, 8, 2); } \
+    else { if (cw == 4) PFHIP_PICK_NF(LN_, FS_, 4, 4); else PFHIP_PICK_NF(LN_, FS_, 8, 4); }                                                              \
+  } while (0)
+  if (ln_colsum) PFHIP_PICK_CW(true, false);
+  else if (fsmn_v) PFHIP_PICK_CW(false, true);
+  else PFHIP_PICK_CW(false, false);
+#undef PFHIP_PICK_CW
+#undef PFHIP_PICK_NF
+#undef PFHIP_PICK_MR
+#undef PFHIP_LAUNCH1T
+  return true;
 }
 
 }  // namespace pfhip

@@ -24,6 +24,7 @@ def _lib():
         lib.pfhip_op_gemm_f32_kind.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_fused_ln_gemm.argtypes = [_vp, _ci, _ci, _vp, _vp, _cf, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp,
                                                _ci, _ci, _ci, _ci, _vp]
+        lib.pfhip_op_fused_gemv_1trip.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _cf, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
         lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
@@ -80,6 +81,28 @@ def fused_ln_gemm(X, W, M, N, g=None, b=None, D=None, bias=None, R1=None, R2=Non
                                       out.stride(0), _p(bias), _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
                                       R2.stride(0) if R2 is not None else 0, _p(fsmn_v), fsmn_v.stride(0) if fsmn_v is not None else 0,
                                       _p(fsmn_w), M, N, K, 1 if relu else 0, _stream()), "fused_ln_gemm")
+    return out
+
+
+def fold_layernorm(W, bias, g, b):
+    """(W', b', colsum) for fused_gemv_1trip's algebraic LayerNorm: W' = W * g, b' = bias + W @ b, colsum = W'.sum(1) — in
+    double, rounded once, as the library does at load (pfhip.cpp)."""
+    Wd = W.double()
+    Wf = (Wd * g.double()[None, :]).float()
+    bf = ((bias.double() if bias is not None else 0.0) + Wd @ b.double()).float()
+    return Wf, bf, Wf.double().sum(1).float()
+
+
+def fused_gemv_1trip(X, W, M, N, bias=None, ln_colsum=None, R1=None, fsmn_v=None, fsmn_w=None, relu=False, out=None, eps=1e-12):
+    """One streaming window (M <= 20): (LN ->) GEMM (+bias +R1 +FSMN memory, ReLU), operands requested in one trip; with
+    ln_colsum, W / bias are the folded ones of fold_layernorm."""
+    K = W.shape[1]
+    if out is None:
+        out = torch.zeros((32, round_up(N, 128)), dtype=torch.float32, device=X.device)
+    _ck(_lib().pfhip_op_fused_gemv_1trip(_p(X), X.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias), _p(ln_colsum), eps,
+                                         _p(R1), R1.stride(0) if R1 is not None else 0, _p(fsmn_v),
+                                         fsmn_v.stride(0) if fsmn_v is not None else 0, _p(fsmn_w), M, N, K, 1 if relu else 0, _stream()),
+        "fused_gemv_1trip")
     return out
 
 

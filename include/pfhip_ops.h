@@ -47,6 +47,14 @@ int pfhip_op_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const
                            float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
                            const float* fsmn_v, int ldv, const float* fsmn_w, int M, int N, int K, int relu, void* stream);
 
+/* The same node group with every operand requested in ONE trip to memory and the LayerNormalization applied algebraically
+ * (M <= 20 rows, K = 64..2048 in the window shapes): when ln_colsum != NULL, W / bias are the gamma / beta-folded weights
+ * (W' = W gamma, b' = b + W beta) and ln_colsum[n] = sum_k W'[n][k]; the LayerNorm is over exactly the K operand columns.
+ * Returns hipErrorInvalidValue for shapes the kernel does not take (callers use pfhip_op_fused_ln_gemm there). */
+int pfhip_op_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, float* C, int ldc, const float* bias,
+                              const float* ln_colsum, float eps, const float* R1, int ldr1, const float* fsmn_v, int ldv,
+                              const float* fsmn_w, int M, int N, int K, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

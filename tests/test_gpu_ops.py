@@ -351,3 +351,56 @@ def test_fused_ln_gemm_one_window(ops, M, N, K, D, ln, fsmn):
                             fsmn_v=dev(V) if fsmn else None, fsmn_w=dev(fw) if fsmn else None, relu=True).cpu().numpy()
     assert np.abs(out[:M, :N] - ref).max() < 5e-5 * np.sqrt(K / 512)
     assert not out[M:].any()                 # rows beyond M are not written
+
+
+@pytest.mark.parametrize("M,N,K,ln,fsmn", [(20, 1536, 512, True, False), (20, 512, 512, False, True), (20, 2048, 512, True, False),
+                                           (20, 512, 2048, False, False), (1, 512, 2048, True, False), (7, 2048, 512, True, False),
+                                           (8, 512, 512, True, False), (13, 16384, 512, False, False), (3, 512, 512, False, True)])
+def test_fused_gemv_one_trip(ops, M, N, K, ln, fsmn):
+    """stream_fused.hip, one-trip form: LayerNorm applied ALGEBRAICALLY on gamma/beta-folded weights (rstd * (x W'^T - mean * colsum)
+    + b', statistics merged with Chan's formula from the same loaded values) -> GEMM (+bias, +residual, ReLU) (+ FSMN memory), against
+    the explicit two-pass LayerNorm in fp64.  Rows with a mean several times their spread, gamma in [0.5, 1.5], beta ~ 0.2."""
+    import torch
+    rng = np.random.default_rng(M * 1000 + N + K)
+    X = np.zeros((32, K), np.float32)
+    X[:M] = (rng.standard_normal((M, K)) * 3 + 4.5).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    g = (rng.random(K) + 0.5).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((32, N)).astype(np.float32)
+    V = rng.standard_normal((32, N)).astype(np.float32)
+    fw = (rng.standard_normal((N, 11)) / 3).astype(np.float32)
+    xd = X[:M].astype(np.float64)
+    if ln:
+        xd = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-12) * g + b
+    ref = xd @ W.astype(np.float64).T + bias + R[:M]
+    if fsmn:
+        mem = V[:M].astype(np.float64).copy()
+        for t in range(M):
+            for j in range(11):
+                s = t + j - 5
+                if 0 <= s < M:
+                    mem[t] += fw[:, j] * V[s]
+        ref = ref + mem
+    ref = np.maximum(ref, 0)
+    Wd, bd, cs = dev(W), dev(bias), None
+    if ln:
+        Wd, bd, cs = ops.fold_layernorm(Wd, bd, dev(g), dev(b))
+    out = torch.zeros((32, N), dtype=torch.float32, device="cuda")
+    ops.fused_gemv_1trip(dev(X), Wd, M, N, bias=bd, ln_colsum=cs, R1=dev(R), fsmn_v=dev(V) if fsmn else None,
+                         fsmn_w=dev(fw) if fsmn else None, relu=True, out=out)
+    out = out.cpu().numpy()
+    # the algebraic form subtracts mean * colsum from the raw dot product: its rounding scales with sqrt(mean^2 + var) / std (~1.8 here)
+    assert np.abs(out[:M] - ref).max() < 1e-4 * np.sqrt(K / 512)
+    assert not out[M:].any()                 # rows beyond M are not written
+
+
+def test_fused_gemv_one_trip_rejects_other_shapes(ops):
+    import torch
+    X = torch.zeros((32, 576), device="cuda"); W = torch.zeros((1536, 576), device="cuda")
+    with pytest.raises(Exception):
+        ops.fused_gemv_1trip(X, W, 20, 1536)          # K = 576: not a whole number of k-blocks
+    X = torch.zeros((32, 512), device="cuda"); W = torch.zeros((512, 512), device="cuda")
+    with pytest.raises(Exception):
+        ops.fused_gemv_1trip(X, W, 21, 512)           # more rows than a window's lanes hold

@@ -42,4 +42,29 @@ for (N, K, ln) in ((1536, 512, True), (512, 512, False), (2048, 512, True), (512
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / n * 1e3)
     t = float(np.median(ts[1:]))
-    print(f"M={M} N={N:5d} K={K:5d} LN={int(ln)}: {t:7.2f} us per launch  ({Np * K * 4 / t / 1e3:7.1f} GB/s of weights)  err {err:.1e}", flush=True)
+    line = f"M={M} N={N:5d} K={K:5d} LN={int(ln)}: {t:7.2f} us per launch  ({Np * K * 4 / t / 1e3:7.1f} GB/s of weights)  err {err:.1e}"
+    # one-trip form (folded weights when LN)
+    if N <= 4096 and M <= 20:
+        if ln:
+            Wf = torch.empty_like(Ws)
+            for cp in reversed(range(copies)):      # ends with copy 0: bf / cs belong to the copy the error check uses
+                Wf[cp], bf, cs = ops.fold_layernorm(Ws[cp], bias, g, b)
+        else:
+            Wf, bf, cs = Ws, bias, None
+        out2 = torch.zeros(32, Np, device="cuda")
+        ops.fused_gemv_1trip(X, Wf[0], M, N, bias=bf, ln_colsum=cs, R1=R, relu=True, out=out2)
+        err2 = float((out2[:M, :N].double() - ref).abs().max())
+        lib.pfhip_dev_fused_gemv_1trip_bench.argtypes = [vp, ci, vp, ci, ctypes.c_size_t, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        ts = []
+        for rep in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.pfhip_dev_fused_gemv_1trip_bench(X.data_ptr(), K, Wf.data_ptr(), K, Np * K, copies, out2.data_ptr(), Np, bf.data_ptr(),
+                                                      cs.data_ptr() if ln else None, R.data_ptr(), Np, M, N, K, 1, n,
+                                                      torch.cuda.current_stream().cuda_stream)
+            e1.record(); torch.cuda.synchronize()
+            assert rc == 0, rc
+            ts.append(e0.elapsed_time(e1) / n * 1e3)
+        t2 = float(np.median(ts[1:]))
+        line += f"   | one trip: {t2:7.2f} us  err {err2:.1e}"
+    print(line, flush=True)

@@ -58,6 +58,11 @@ int pfhip_dev_fused_gemv_1trip_bench(const float* X, int ldx, const float* W, in
       return (int)hipErrorInvalidValue;
   return done();
 }
+int pfhip_op_window_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int Lq, int Lk,
+                              int H, float scale, void* stream) {
+  if (!pfhip::launch_window_attention(Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk, H, scale, S(stream))) return (int)hipErrorInvalidValue;
+  return done();
+}
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream) {
   if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;

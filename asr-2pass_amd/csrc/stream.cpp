@@ -290,8 +290,10 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
                  m->d_lns_qkv + (size_t)i * 3 * d, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, d, false))
         ln_gemm(xin, ldin, Din, p + "norm1", first ? m->d_w0qkv : m->W(p + "qkv.w").d, Kp, m->qkv.f(), 3 * d, m->W(p + "qkv.b").d,
                 nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, Kp, false);
-      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
-                              d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+      if (!pfhip::launch_window_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, M, M, c.n_head,
+                                          att_scale, st))
+        pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                                d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
       if (!gemv1(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, nullptr, first ? nullptr : x, d, m->qkv.f() + 2 * d,
                  3 * d, m->W(p + "fsmn.w").d, M, d, d, false))
         ln_gemm(m->ctx.f(), d, 0, "", m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, nullptr, 0,
@@ -427,8 +429,9 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
         ln_gemm(xd, d, d, p + "norm3", m->W(p + "q.w").d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, nullptr, 0,
                 nullptr, ML, d, d, false);
       const float* kvl = m->kvall.f() + (size_t)i * 2 * d;
-      pfhip::launch_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
-                              c.n_head, maxN, att_scale, st);
+      if (!pfhip::launch_window_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, ML, M, c.n_head, att_scale, st))
+        pfhip::launch_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
+                                c.n_head, maxN, att_scale, st);
       if (!gemv1(m->ctxd.f(), d, m->W(p + "out.w").d, d, xd, d, m->W(p + "out.b").d, nullptr, xd, d, nullptr, 0, nullptr, ML, d, d, false))
         ln_gemm(m->ctxd.f(), d, 0, "", m->W(p + "out.w").d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, nullptr, 0, nullptr,
                 ML, d, d, false);

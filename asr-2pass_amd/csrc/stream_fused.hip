@@ -429,6 +429,83 @@ __global__ __launch_bounds__(1024) void fused_gemv1t_kernel(
   C[(size_t)erow * ldc + gcol] = v;
 }
 
+
+// ---- attention over ONE window ----------------------------------------------------------------------------------------------
+// O[q, h*128:(h+1)*128] = softmax(scale * Q_h K_h^T) V_h for Lq <= 32 queries and Lk <= 32 keys (the encoder's self-attention over a
+// 20-row window; the decoder's few tokens against it), d_k = 128.  The general kernel (attention.hip) is built for hundreds of
+// keys — query blocks, K/V tiles through LDS, online softmax — and takes 8.6 us here; this one is one workgroup per head, four
+// waves: every operand is requested at kernel start (Q / K fragments of the wave's 32-wide slice of d, the V rows of its 32-wide
+// slice of the output), scores = four partial 32 x 32 tiles on the fp32 MFMA summed through LDS, one softmax pass with 32 lanes per
+// query, P V as ceil(Lk / 2) MFMAs per wave.  Same arithmetic type as the general kernel (fp32 MFMA = fmaf chains, exp2).
+__global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+                                                               const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
+                                                               int Lq, int Lk, float scale_log2e) {
+  __shared__ float sp[4][32][33];
+  __shared__ float P[32][33];
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 qf[4], kf[4];
+  const float* qp = Q + (size_t)(r < Lq ? r : 0) * ldq + h * 128 + w * 32 + 4 * hh;
+  const float* kp = K + (size_t)(r < Lk ? r : 0) * ldk + h * 128 + w * 32 + 4 * hh;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    qf[u] = r < Lq ? *reinterpret_cast<const float4*>(qp + 8 * u) : zero4;
+    kf[u] = r < Lk ? *reinterpret_cast<const float4*>(kp + 8 * u) : zero4;
+  }
+  float vf[16];
+#pragma unroll
+  for (int st = 0; st < 16; ++st) {
+    const int key = 2 * st + hh;
+    vf[st] = key < Lk ? V[(size_t)key * ldv + h * 128 + w * 32 + r] : 0.f;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].x, kf[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].y, kf[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].z, kf[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].w, kf[u].w, acc, 0, 0, 0);
+  }
+  // D[i = query][j = key]: j = lane & 31, i = (e & 3) + 8 * (e >> 2) + 4 * hh
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sp[w][(e & 3) + 8 * (e >> 2) + 4 * hh][r] = acc[e];
+  __syncthreads();
+  for (int row = tid >> 5; row < Lq; row += 8) {          // 32 lanes per query
+    const int k = tid & 31;
+    float sc = ((sp[0][row][k] + sp[1][row][k]) + (sp[2][row][k] + sp[3][row][k])) * scale_log2e;
+    if (k >= Lk) sc = -INFINITY;
+    float mx = sc;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float ex = k < Lk ? exp2f(sc - mx) : 0.f;
+    float sum = ex;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    P[row][k] = ex / sum;
+  }
+  __syncthreads();
+  f32x16 o2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o2[e] = 0.f;
+  const int steps = (Lk + 1) >> 1;
+#pragma unroll
+  for (int st = 0; st < 16; ++st) {
+    if (st < steps) {
+      const float a = r < Lq ? P[r][2 * st + hh] : 0.f;   // keys >= Lk carry probability 0 (P's row was written up to column 31)
+      o2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vf[st], o2, 0, 0, 0);
+    }
+  }
+  // D[i = query][j = d]: a wave stores 32 consecutive floats per (e, hh)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int q = (e & 3) + 8 * (e >> 2) + 4 * hh;
+    if (q < Lq) O[(size_t)q * ldo + h * 128 + w * 32 + r] = o2[e];
+  }
+}
+
 }  // namespace
 
 template <bool LN, int CW>
@@ -520,6 +597,17 @@ bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, f
 #undef PFHIP_PICK_NF
 #undef PFHIP_PICK_MR
 #undef PFHIP_LAUNCH1T
+  return true;
+}
+
+// window_attention_kernel: false when the shape is outside what it takes (the caller uses launch_attention).
+// PFHIP_STREAM_WATT=0 turns it off.
+bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int Lq, int Lk,
+                             int H, float scale, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("PFHIP_STREAM_WATT"); return !(e && e[0] == '0'); }();
+  if (!on || Lq < 1 || Lq > 32 || Lk < 1 || Lk > 32 || H < 1) return false;
+  hipLaunchKernelGGL(window_attention_kernel, dim3(H), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk,
+                     scale * 1.4426950408889634f);
   return true;
 }
 

@@ -25,6 +25,7 @@ def _lib():
         lib.pfhip_op_fused_ln_gemm.argtypes = [_vp, _ci, _ci, _vp, _vp, _cf, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp,
                                                _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_fused_gemv_1trip.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _cf, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp]
+        lib.pfhip_op_window_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
         lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
@@ -129,6 +130,14 @@ def attention(Q, K, V, q_off, q_len, kv_off, kv_len, n_head, scale, head_dim=128
     _ck(_lib().pfhip_op_attention_hd(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                      _p(q_off), _p(q_len), _p(kv_off), _p(kv_len), B, n_head, int(q_len.max().item()),
                                      scale, head_dim, _stream()), "attention")
+    return O
+
+
+def window_attention(Q, K, V, Lq, Lk, n_head, scale):
+    """One streaming window: softmax(scale Q_h K_h^T) V_h for rows [0, Lq) x [0, Lk), d_k = 128."""
+    O = torch.zeros((Q.shape[0], n_head * 128), dtype=torch.float32, device=Q.device)
+    _ck(_lib().pfhip_op_window_attention(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0), Lq, Lk, n_head,
+                                         scale, _stream()), "window_attention")
     return O
 
 

@@ -55,6 +55,12 @@ int pfhip_op_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, 
                               const float* ln_colsum, float eps, const float* R1, int ldr1, const float* fsmn_v, int ldv,
                               const float* fsmn_w, int M, int N, int K, int relu, void* stream);
 
+/* MatMul-Softmax-MatMul of ONE streaming window: Lq <= 32 queries against Lk <= 32 keys (rows 0.. of the given pointers), H heads of
+ * d_k = 128 (the streaming encoder's self-attention over its 20-row window, the decoder's tokens against it:
+ * onnxruntime/src/paraformer-online.cpp:426-515).  hipErrorInvalidValue for other shapes (callers use pfhip_op_attention). */
+int pfhip_op_window_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int Lq, int Lk,
+                              int H, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,3 +404,25 @@ def test_fused_gemv_one_trip_rejects_other_shapes(ops):
     X = torch.zeros((32, 512), device="cuda"); W = torch.zeros((512, 512), device="cuda")
     with pytest.raises(Exception):
         ops.fused_gemv_1trip(X, W, 21, 512)           # more rows than a window's lanes hold
+
+
+@pytest.mark.parametrize("Lq,Lk,H", [(20, 20, 4), (1, 20, 4), (7, 20, 4), (32, 32, 4), (10, 10, 4), (3, 1, 2), (20, 13, 4)])
+def test_window_attention(ops, Lq, Lk, H):
+    """stream_fused.hip window_attention_kernel (one streaming window, d_k = 128) against softmax(QK^T)V in fp64; Q / K / V as column
+    blocks of one row-major buffer, as the streaming encoder hands them over; large score range."""
+    import torch
+    rng = np.random.default_rng(Lq * 100 + Lk)
+    d = H * 128
+    qkv = (rng.standard_normal((32, 3 * d)) * 2.0).astype(np.float32)
+    t = dev(qkv)
+    out = ops.window_attention(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], Lq, Lk, H, 128 ** -0.5).cpu().numpy()
+    for h in range(H):
+        q = qkv[:Lq, h * 128:(h + 1) * 128].astype(np.float64)
+        k = qkv[:Lk, d + h * 128:d + (h + 1) * 128].astype(np.float64)
+        v = qkv[:Lk, 2 * d + h * 128:2 * d + (h + 1) * 128].astype(np.float64)
+        sc = q @ k.T * 128 ** -0.5
+        p = np.exp(sc - sc.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
+        assert np.abs(out[:Lq, h * 128:(h + 1) * 128] - p @ v).max() < 2e-5
+    assert not out[Lq:].any()
+    with pytest.raises(Exception):
+        ops.window_attention(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], 33, 20, H, 1.0)

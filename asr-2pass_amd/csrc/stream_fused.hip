@@ -1,23 +1,19 @@
 // Fused kernels for ONE streaming window (`ForwardChunk`'s encoder and decoder Runs,
 // onnxruntime/src/paraformer-online.cpp:426-515, at M = 20 rows / a handful of tokens).
 //
-// A lone 600-ms chunk is neither compute- nor bandwidth-bound: it reads 0.88 GB of weights behind ~700 DEPENDENT launches
-// of ~7 us each (5 ms per chunk, 2 % of the HBM roofline).  A dependent launch costs its boundary (1.5-2 us) plus a kernel
-// that cannot be shorter than a few memory latencies, so the lever is the NUMBER of launches, and grid-wide barriers inside
-// one launch cost more than a boundary (MI355X_MICROARCH.md price list: barrier-xcd 4-5 us) — so the fusion has to respect
-// the data dependences between whole matrices.  What can be fused without any cross-workgroup exchange:
-//   * a row-wise operator in front of a GEMM is RECOMPUTED by every workgroup of that GEMM (20 x 512 elements: nothing):
-//     LayerNorm -> GEMM is one launch (`fused_ln_gemm_kernel`);
-//   * everything between two GEMMs that only needs whole small matrices is recomputed the same way: the encoder's
-//     FSMN memory + 4-head self-attention over the window + output projection + residuals is one launch
-//     (`fused_att_out_kernel`): every workgroup redoes the 20 x 20 attention (0.8 MFLOP) and then streams its own 32-column
-//     slice of W_o;
-//   * the decoder's norm2 -> cached FSMN -> residual -> norm3 -> q-projection chain likewise (`fused_dec_mid_kernel`), and
-//     cross-attention + output projection + residual (`fused_cross_out_kernel`); the 16 layers' K/V projections of the
-//     (fixed) encoder window are one GEMM over the concatenated weights.
-// An encoder layer becomes 4 launches (was 8), a decoder layer 4 (was 11).  Arithmetic: fp32 MFMA (`v_mfma_f32_32x32x2_f32`)
-// exactly as the weight-streaming GEMM of gemm.hip (K split over 16 waves, operands streamed straight into VGPRs, partial
-// tiles summed through LDS); LayerNorm two-pass in fp32 like rowops.hip.
+// A lone 600-ms chunk is neither compute- nor bandwidth-bound: it reads 0.88 GB of weights behind several hundred DEPENDENT
+// launches.  A dependent launch costs its boundary (1.5-2 us) plus a kernel that cannot be shorter than one memory latency, and
+// grid-wide barriers inside one launch cost more than a boundary (MI355X_MICROARCH.md price list: barrier-xcd 4-5 us) — so the
+// fusion respects the data dependences between whole matrices, and what is left is (a) the number of launches and (b) the
+// number of dependent round trips inside each.
+//   (a) a row-wise operator in front of a GEMM is RECOMPUTED by every workgroup of that GEMM (20 x 512 elements: nothing):
+//       LayerNorm -> GEMM is one launch; the SAN-M FSMN memory is an epilogue term of the output projection; the 16 decoder
+//       layers' K/V projections of the (fixed) window are one GEMM over the concatenated weights (stream.cpp).
+//   (b) three generations of the LN -> GEMM (+bias, residual, FSMN, ReLU) launch, newest last:
+//       fused_ln_gemm_kernel   fp32 MFMA, K split over 16 waves (kept for the vocabulary projection and odd shapes),
+//       fused_ln_gemv_kernel   the same on the vector ALUs with LayerNorm on load (fallback: K = 576 first layer, M > 20),
+//       fused_gemv1t_kernel    every operand of a lane requested at kernel start, LayerNorm applied algebraically;
+//       and window_attention_kernel for the 20 x 20 attention between them.
 // All kernels take M <= 32 rows (one window of the [5,10,5] chunking is 20).
 #include "kernels.h"
 

@@ -211,6 +211,11 @@ void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const 
 // operands requested at kernel start (stream_fused.hip).  Returns false for shapes it does not take.
 bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int Lq, int Lk,
                              int H, float scale, hipStream_t s);
+// The window's attention AND the projection of its context by W [N, 512] (+bias, +R1, + the FSMN memory of fsmn_v) in one launch:
+// every workgroup redoes the attention and keeps the context in LDS (stream_fused.hip).  H = 4 heads of 128, Lq <= 20, Lk <= 32.
+bool launch_fused_att_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int Lq, int Lk, int H, float scale,
+                          const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* fsmn_v,
+                          int ldfv, const float* fsmn_w, int N, hipStream_t s);
 // the same operator with every operand requested in one trip and LayerNorm applied algebraically (stream_fused.hip): W / bias are
 // the gamma/beta-folded ones and ln_colsum their column sums when the LayerNorm is wanted.  Returns false for shapes it does not take.
 bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, float* C, int ldc, const float* bias, const float* ln_colsum,

@@ -63,6 +63,13 @@ int pfhip_op_window_attention(const float* Q, int ldq, const float* K, int ldk, 
   if (!pfhip::launch_window_attention(Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk, H, scale, S(stream))) return (int)hipErrorInvalidValue;
   return done();
 }
+int pfhip_op_fused_att_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int Lq, int Lk, int H, float scale,
+                           const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* fsmn_v,
+                           int ldfv, const float* fsmn_w, int N, void* stream) {
+  if (!pfhip::launch_fused_att_out(Q, ldq, K, ldk, V, ldv, Lq, Lk, H, scale, W, ldw, C, ldc, bias, R1, ldr1, fsmn_v, ldfv, fsmn_w, N, S(stream)))
+    return (int)hipErrorInvalidValue;
+  return done();
+}
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream) {
   if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;

@@ -265,6 +265,7 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   // row-wise operators are folded into the GEMMs that consume them.  PFHIP_STREAM_FUSED=0 keeps the general path.
   static const bool fused_on = [] { const char* e = getenv("PFHIP_STREAM_FUSED"); return !(e && e[0] == '0'); }();
   const bool lean = fused_on && B == 1 && M <= 32;
+  static const bool att_out_on = [] { const char* e = getenv("PFHIP_STREAM_ATT_OUT"); return e && e[0] == '1'; }();
   auto ln_gemm = [&](const float* X, int ldx, int D, const std::string& norm, const float* Wd, int ldw, float* Cd, int ldc,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, const float* fv, int ldv,
                      const float* fw, int rows, int N, int K, bool relu) {
@@ -290,14 +291,20 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
                  m->d_lns_qkv + (size_t)i * 3 * d, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, d, false))
         ln_gemm(xin, ldin, Din, p + "norm1", first ? m->d_w0qkv : m->W(p + "qkv.w").d, Kp, m->qkv.f(), 3 * d, m->W(p + "qkv.b").d,
                 nullptr, 0, nullptr, 0, nullptr, 0, nullptr, M, 3 * d, Kp, false);
-      if (!pfhip::launch_window_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, M, M, c.n_head,
-                                          att_scale, st))
-        pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
-                                d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
-      if (!gemv1(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, nullptr, first ? nullptr : x, d, m->qkv.f() + 2 * d,
-                 3 * d, m->W(p + "fsmn.w").d, M, d, d, false))
-        ln_gemm(m->ctx.f(), d, 0, "", m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, nullptr, 0,
-                m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, M, d, d, false);
+      // attention + output projection + FSMN memory + residual as one launch (every workgroup redoes the attention) is opt-in:
+      // measured slower than the two launches (stream_fused.hip, launch_fused_att_out)
+      if (!att_out_on || !pfhip::launch_fused_att_out(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, M, M, c.n_head, att_scale,
+                                       m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, m->qkv.f() + 2 * d,
+                                       3 * d, m->W(p + "fsmn.w").d, d, st)) {
+        if (!pfhip::launch_window_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, M, M,
+                                            c.n_head, att_scale, st))
+          pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                                  d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+        if (!gemv1(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, nullptr, first ? nullptr : x, d, m->qkv.f() + 2 * d,
+                   3 * d, m->W(p + "fsmn.w").d, M, d, d, false))
+          ln_gemm(m->ctx.f(), d, 0, "", m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, first ? nullptr : x, d, nullptr, 0,
+                  m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, M, d, d, false);
+      }
       if (!m->d_lnw_ffn1 ||
           !gemv1(x, d, m->d_lnw_ffn1 + (size_t)i * c.ffn * d, d, m->hbuf.f(), c.ffn, m->d_lnb_ffn1 + (size_t)i * c.ffn,
                  m->d_lns_ffn1 + (size_t)i * c.ffn, nullptr, 0, nullptr, 0, nullptr, M, c.ffn, d, true))
@@ -429,6 +436,9 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
         ln_gemm(xd, d, d, p + "norm3", m->W(p + "q.w").d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, nullptr, 0,
                 nullptr, ML, d, d, false);
       const float* kvl = m->kvall.f() + (size_t)i * 2 * d;
+      if (att_out_on && pfhip::launch_fused_att_out(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, ML, M, c.n_head, att_scale, m->W(p + "out.w").d, d, xd, d,
+                                      m->W(p + "out.b").d, xd, d, nullptr, 0, nullptr, d, st))
+        continue;
       if (!pfhip::launch_window_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, ML, M, c.n_head, att_scale, st))
         pfhip::launch_attention(m->qd.f(), d, kvl, kv_ld, kvl + d, kv_ld, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
                                 c.n_head, maxN, att_scale, st);

@@ -502,6 +502,148 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
   }
 }
 
+
+// ---- attention of one window + output projection (+ FSMN memory, + residual) in ONE launch -----------------------------------------
+// The projection's operand is the whole context matrix (all four heads), so every workgroup of the projection redoes the window's
+// attention (4 heads x 32 x 32 x 128 x 2 products: 1 MFLOP padded, ~3 us of fp32 MFMA on one CU) and keeps the result in LDS — against
+// a launch boundary, a wave ramp and a second trip to memory for a separate attention kernel.  16 waves = 4 heads x 4 (d-quarters for
+// the scores, 32-wide output slices for P V) exactly as window_attention_kernel; the GEMV part is fused_gemv1t_kernel's
+// <CW 4, 2 columns per lane, 4 row groups, 8 k-subsets> shape with the activation float4s read from LDS.  d_model = 4 x 128.
+template <bool FS, int RPL>
+__global__ __launch_bounds__(1024) void fused_att_out_kernel(
+    const float* __restrict__ Q, int ldq, const float* __restrict__ Kx, int ldk, const float* __restrict__ Vx, int ldv, int Lq, int Lk,
+    float scale_log2e, const float* __restrict__ W, int ldw, float* C, int ldc, const float* __restrict__ bias, const float* R1, int ldr1,
+    const float* __restrict__ FV, int ldfv, const float* __restrict__ fw, int N) {
+  constexpr int CW = 4, CPL = 2, CG = 2, RG = 4, MR = RG * RPL, D = 512, CS = D + 4;      // 8 k-subsets of 4 k per wave
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const ctx = reinterpret_cast<float*>(lds_raw);                         // [32][CS]; the score partials live here first
+  float (*sp)[4][32][33] = reinterpret_cast<float (*)[4][32][33]>(lds_raw);     // [head][d-quarter][query][key]
+  float (*P)[32][33] = reinterpret_cast<float (*)[32][33]>(lds_raw + 4 * 4 * 32 * 33 * 4);   // [head][query][key]
+  float (*red)[MR * CW] = reinterpret_cast<float (*)[MR * CW]>(lds_raw + 4 * 4 * 32 * 33 * 4 + 4 * 32 * 33 * 4);
+  static_assert(32 * CS * 4 <= 4 * 4 * 32 * 33 * 4, "context tile must fit where the score partials were");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = wave >> 2, w = wave & 3, r = lane & 31, hh = lane >> 5;
+  const int cg = lane % CG, rg = (lane / CG) % RG, ks = lane / (CG * RG);
+  const int n0 = blockIdx.x * CW;
+  const int k = wave * 32 + ks * 4;
+  // every operand of the launch, requested together
+  f32x4 wv[CPL];
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc)
+    wv[cc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)(n0 + cg * CPL + cc) * ldw + k));
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 qf[4], kf[4];
+  const float* qp = Q + (size_t)(r < Lq ? r : 0) * ldq + h * 128 + w * 32 + 4 * hh;
+  const float* kp = Kx + (size_t)(r < Lk ? r : 0) * ldk + h * 128 + w * 32 + 4 * hh;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    qf[u] = r < Lq ? *reinterpret_cast<const float4*>(qp + 8 * u) : zero4;
+    kf[u] = r < Lk ? *reinterpret_cast<const float4*>(kp + 8 * u) : zero4;
+  }
+  float vf[16];
+#pragma unroll
+  for (int st = 0; st < 16; ++st) {
+    const int key = 2 * st + hh;
+    vf[st] = key < Lk ? Vx[(size_t)key * ldv + h * 128 + w * 32 + r] : 0.f;
+  }
+  const int erow = tid / CW, ecol = tid % CW, gcol = n0 + ecol;
+  const bool fin = tid < MR * CW && erow < Lq && gcol < N;
+  float e_bias = 0.f, e_r1 = 0.f;
+  float fv[11], fk[11];
+  if (fin) {
+    if (bias) e_bias = bias[gcol];
+    if (R1) e_r1 = R1[(size_t)erow * ldr1 + gcol];
+  }
+  if (FS) {
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int t = erow + j - 5;
+      const bool in = fin && t >= 0 && t < Lq;
+      fv[j] = in ? FV[(size_t)t * ldfv + gcol] : 0.f;
+      fk[j] = fin ? fw[gcol * 11 + j] : 0.f;
+    }
+  }
+  // ---- scores: four partial tiles per head
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].x, kf[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].y, kf[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].z, kf[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[u].w, kf[u].w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sp[h][w][(e & 3) + 8 * (e >> 2) + 4 * hh][r] = acc[e];
+  __syncthreads();
+  // ---- softmax: 32 lanes per (head, query); 4 x Lq rows over 32 half-waves
+  for (int row = tid >> 5; row < 4 * Lq; row += 32) {
+    const int hd = row / Lq, q = row - hd * Lq, kk = tid & 31;
+    float sc = ((sp[hd][0][q][kk] + sp[hd][1][q][kk]) + (sp[hd][2][q][kk] + sp[hd][3][q][kk])) * scale_log2e;
+    if (kk >= Lk) sc = -INFINITY;
+    float mx = sc;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float ex = kk < Lk ? exp2f(sc - mx) : 0.f;
+    float sum = ex;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    P[hd][q][kk] = ex / sum;
+  }
+  __syncthreads();                       // probabilities complete; the score partials are dead: ctx may overwrite them
+  f32x16 o2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o2[e] = 0.f;
+  const int steps = (Lk + 1) >> 1;
+#pragma unroll
+  for (int st = 0; st < 16; ++st) {
+    if (st < steps) {
+      const float a = r < Lq ? P[h][r][2 * st + hh] : 0.f;
+      o2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vf[st], o2, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ctx[((e & 3) + 8 * (e >> 2) + 4 * hh) * CS + h * 128 + w * 32 + r] = o2[e];
+  __syncthreads();
+  // ---- projection: this lane's RPL rows x CPL columns over its 4 k
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    const int row = rg * RPL + i;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ctx + (row < Lq ? row : Lq - 1) * CS + k);
+    float d[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) {
+      d[cc] = a[0] * wv[cc][0];
+      d[cc] = fmaf(a[1], wv[cc][1], d[cc]); d[cc] = fmaf(a[2], wv[cc][2], d[cc]); d[cc] = fmaf(a[3], wv[cc][3], d[cc]);
+    }
+#pragma unroll
+    for (int o = CG * RG; o < 64; o <<= 1) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) d[cc] += __shfl_xor(d[cc], o);
+    }
+    if (ks == 0) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) red[wave][row * CW + cg * CPL + cc] = d[cc];
+    }
+  }
+  __syncthreads();
+  if (!fin) return;
+  float v = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < kWaves; ++w2) v += red[w2][tid];
+  v += e_bias;
+  v += e_r1;
+  if (FS) {
+    float mem = fv[5];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) mem += fk[j] * fv[j];
+    v += mem;
+  }
+  C[(size_t)erow * ldc + gcol] = v;
+}
+
 }  // namespace
 
 template <bool LN, int CW>
@@ -604,6 +746,37 @@ bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, c
   if (!on || Lq < 1 || Lq > 32 || Lk < 1 || Lk > 32 || H < 1) return false;
   hipLaunchKernelGGL(window_attention_kernel, dim3(H), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk,
                      scale * 1.4426950408889634f);
+  return true;
+}
+
+// fused_att_out_kernel: attention of one window (Lq <= 20 queries, Lk <= 32 keys, 4 heads of 128) + projection by W [N, 512]
+// (+bias, +R1, + FSMN memory of fsmn_v over the Lq rows).  False when the shape is outside what it takes, and in the streaming
+// path unless PFHIP_STREAM_ATT_OUT=1: measured, the fused launch costs ~17 us where window_attention_kernel (7.1) + boundary (1.5) +
+// projection (5.4) cost 14 — 128 workgroups x 16 waves each redoing 3 us of fp32 MFMA and 24 operand loads per lane is more than
+// the launch it saves (2.92 against 2.70 ms per chunk on the same box).  Kept, tested, as the record of that.
+bool launch_fused_att_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int Lq, int Lk, int H, float scale,
+                          const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* fsmn_v,
+                          int ldfv, const float* fsmn_w, int N, hipStream_t s) {
+  if (H != 4 || Lq < 1 || Lq > 20 || Lk < 1 || Lk > 32 || N < 4 || N % 4) return false;
+  const size_t lds = (size_t)4 * 4 * 32 * 33 * 4 + 4 * 32 * 33 * 4 + (size_t)kWaves * 20 * 4 * 4;       // 89,600 B
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_done.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_att_out_kernel<true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_att_out_kernel<false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_att_out_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_att_out_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  const float sl = scale * 1.4426950408889634f;
+  const dim3 grid(N / 4), block(1024);
+#define PFHIP_LAUNCH_AO(FS_, RPL_)                                                                                                    \
+  hipLaunchKernelGGL((fused_att_out_kernel<FS_, RPL_>), grid, block, lds, s, Q, ldq, K, ldk, V, ldv, Lq, Lk, sl, W, ldw, C, ldc, bias, R1, \
+                     ldr1, fsmn_v, ldfv, fsmn_w, N)
+  if (fsmn_v) { if (Lq <= 8) PFHIP_LAUNCH_AO(true, 2); else PFHIP_LAUNCH_AO(true, 5); }
+  else { if (Lq <= 8) PFHIP_LAUNCH_AO(false, 2); else PFHIP_LAUNCH_AO(false, 5); }
+#undef PFHIP_LAUNCH_AO
   return true;
 }
 

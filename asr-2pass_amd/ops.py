@@ -26,6 +26,8 @@ def _lib():
                                                _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_fused_gemv_1trip.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _cf, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp]
         lib.pfhip_op_window_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _cf, _vp]
+        lib.pfhip_op_fused_att_out.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _cf, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp,
+                                               _ci, _vp]
         lib.pfhip_op_layernorm.argtypes = [_vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
         lib.pfhip_op_fsmn.argtypes = [_vp, _ci, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp]
         lib.pfhip_op_attention.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]
@@ -139,6 +141,17 @@ def window_attention(Q, K, V, Lq, Lk, n_head, scale):
     _ck(_lib().pfhip_op_window_attention(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0), Lq, Lk, n_head,
                                          scale, _stream()), "window_attention")
     return O
+
+
+def fused_att_out(Q, K, V, Lq, Lk, n_head, scale, W, bias=None, R1=None, fsmn_v=None, fsmn_w=None, out=None):
+    """One streaming window: attention (Lq x Lk, 4 heads of 128) and the projection of its context by W [N, 512] in one launch."""
+    N = W.shape[0]
+    if out is None:
+        out = torch.zeros((32, N), dtype=torch.float32, device=Q.device)
+    _ck(_lib().pfhip_op_fused_att_out(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), Lq, Lk, n_head, scale, _p(W), W.stride(0),
+                                      _p(out), out.stride(0), _p(bias), _p(R1), R1.stride(0) if R1 is not None else 0, _p(fsmn_v),
+                                      fsmn_v.stride(0) if fsmn_v is not None else 0, _p(fsmn_w), N, _stream()), "fused_att_out")
+    return out
 
 
 def cif(hidden, alphas, row_off, length, threshold, tail):

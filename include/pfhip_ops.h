@@ -61,6 +61,12 @@ int pfhip_op_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, 
 int pfhip_op_window_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int Lq, int Lk,
                               int H, float scale, void* stream);
 
+/* The window's MatMul-Softmax-MatMul AND the MatMul/Gemm that projects its context (W [N, 512]; +bias, +residual Add, + the SAN-M
+ * FSMN memory of fsmn_v over the Lq rows) in ONE launch: H = 4 heads of 128, Lq <= 20, Lk <= 32.  hipErrorInvalidValue otherwise. */
+int pfhip_op_fused_att_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int Lq, int Lk, int H, float scale,
+                           const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* fsmn_v,
+                           int ldfv, const float* fsmn_w, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -426,3 +426,42 @@ def test_window_attention(ops, Lq, Lk, H):
     assert not out[Lq:].any()
     with pytest.raises(Exception):
         ops.window_attention(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], 33, 20, H, 1.0)
+
+
+@pytest.mark.parametrize("Lq,Lk,fsmn", [(20, 20, True), (1, 20, False), (7, 20, False), (10, 10, True), (20, 13, False), (3, 32, False)])
+def test_fused_attention_and_projection(ops, Lq, Lk, fsmn):
+    """stream_fused.hip fused_att_out_kernel: the window's attention (4 heads of 128) and the projection of its context (+bias,
+    +residual, + FSMN memory of the value block) in one launch, against fp64."""
+    import torch
+    rng = np.random.default_rng(Lq * 100 + Lk + 7)
+    H, d, N = 4, 512, 512
+    qkv = (rng.standard_normal((32, 3 * d)) * 1.5).astype(np.float32)
+    W = (rng.standard_normal((N, d)) / np.sqrt(d)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((32, N)).astype(np.float32)
+    fw = (rng.standard_normal((N, 11)) / 3).astype(np.float32)
+    ctx = np.zeros((Lq, d))
+    for h in range(H):
+        q = qkv[:Lq, h * 128:(h + 1) * 128].astype(np.float64)
+        k = qkv[:Lk, d + h * 128:d + (h + 1) * 128].astype(np.float64)
+        v = qkv[:Lk, 2 * d + h * 128:2 * d + (h + 1) * 128].astype(np.float64)
+        sc = q @ k.T * 128 ** -0.5
+        p = np.exp(sc - sc.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
+        ctx[:, h * 128:(h + 1) * 128] = p @ v
+    ref = ctx @ W.astype(np.float64).T + bias + R[:Lq]
+    if fsmn:
+        V = qkv[:, 2 * d:].astype(np.float64)
+        mem = V[:Lq].copy()
+        for t in range(Lq):
+            for j in range(11):
+                s = t + j - 5
+                if 0 <= s < Lq:
+                    mem[t] += fw[:, j] * V[s]
+        ref = ref + mem
+    t = dev(qkv)
+    out = ops.fused_att_out(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], Lq, Lk, H, 128 ** -0.5, dev(W), bias=dev(bias), R1=dev(R),
+                            fsmn_v=t[:, 2 * d:] if fsmn else None, fsmn_w=dev(fw) if fsmn else None).cpu().numpy()
+    assert np.abs(out[:Lq] - ref).max() < 5e-5
+    assert not out[Lq:].any()
+    with pytest.raises(Exception):
+        ops.fused_att_out(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], 21, 20, H, 1.0, dev(W))

@@ -89,26 +89,35 @@ __global__ __launch_bounds__(512, 1) void attention_x6_kernel(
         const int t = t0 - 5 + j;
         rows[j] = (t < 0 || t >= Lk) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(V + (kbase + t) * ldv + c);
       }
+      // mem_accumulate: mem IS the residual stream, x += memory (each element has exactly one owner).  Its old values are
+      // requested eight rows at a time BEFORE the stores of those rows: a load behind a store to the same array cannot be
+      // hoisted by the compiler, and one load -> wait -> store per row was sixteen memory latencies in a row.
 #pragma unroll
-      for (int s = 0; s < kStrip; ++s) {
-        const int t = t0 + s;
-        if (t < Lk) {
-          float4 o = rows[s + 5];
-          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = 0; s0 < kStrip; s0 += 8) {
+        float4 xo[8];
 #pragma unroll
-          for (int j = 0; j < kTaps; ++j) {
-            a.x += wk[0][j] * rows[s + j].x;
-            a.y += wk[1][j] * rows[s + j].y;
-            a.z += wk[2][j] * rows[s + j].z;
-            a.w += wk[3][j] * rows[s + j].w;
+        for (int s = 0; s < 8; ++s) {
+          const int t = t0 + s0 + s;
+          xo[s] = (mem_accumulate && t < Lk) ? *reinterpret_cast<const float4*>(mem + (kbase + t) * ldmem + c)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s1 = 0; s1 < 8; ++s1) {
+          const int s = s0 + s1, t = t0 + s;
+          if (t < Lk) {
+            float4 o = rows[s + 5];
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < kTaps; ++j) {
+              a.x += wk[0][j] * rows[s + j].x;
+              a.y += wk[1][j] * rows[s + j].y;
+              a.z += wk[2][j] * rows[s + j].z;
+              a.w += wk[3][j] * rows[s + j].w;
+            }
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            if (mem_accumulate) { o.x += xo[s1].x; o.y += xo[s1].y; o.z += xo[s1].z; o.w += xo[s1].w; }
+            *reinterpret_cast<float4*>(mem + (kbase + t) * ldmem + c) = o;
           }
-          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-          float4* dst = reinterpret_cast<float4*>(mem + (kbase + t) * ldmem + c);
-          if (mem_accumulate) {            // mem IS the residual stream: x += memory (each element has exactly one owner)
-            const float4 xo = *dst;
-            o.x += xo.x; o.y += xo.y; o.z += xo.z; o.w += xo.w;
-          }
-          *dst = o;
         }
       }
     }

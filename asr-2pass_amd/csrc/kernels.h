@@ -211,6 +211,9 @@ void launch_fused_ln_gemm(const float* X, int ldx, int D, const float* g, const 
 // operands requested at kernel start (stream_fused.hip).  Returns false for shapes it does not take.
 bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int Lq, int Lk,
                              int H, float scale, hipStream_t s);
+bool launch_window_attention_segments(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                                      const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                                      int max_q_len, int max_kv_len, float scale, hipStream_t s);
 // The window's attention AND the projection of its context by W [N, 512] (+bias, +R1, + the FSMN memory of fsmn_v) in one launch:
 // every workgroup redoes the attention and keeps the context in LDS (stream_fused.hip).  H = 4 heads of 128, Lq <= 20, Lk <= 32.
 bool launch_fused_att_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int Lq, int Lk, int H, float scale,

@@ -320,8 +320,11 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
          m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
     pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, B, maxn, d, st);
-    pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
-                            d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+    // windows of <= 32 rows: one small workgroup per (head, connection) instead of the long-sequence kernel
+    if (!pfhip::launch_window_attention_segments(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                                                 d_len, d_off, d_len, B, c.n_head, maxn, maxn, att_scale, st))
+      pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
+                              d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
     gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
          first ? nullptr : x, d, M, false);
     lnorm(m, st, x, d, m->y.f(), d, p + "norm2", M, d, d);
@@ -451,8 +454,10 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     gemm(m, st, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, ML, false);
     gemm(m, st, m->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, M,
          false);
-    pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
-                            c.n_head, maxN, att_scale, st);
+    if (!pfhip::launch_window_attention_segments(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off,
+                                                 d_len, B, c.n_head, maxN, maxn, att_scale, st))
+      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, d_tok_off, d_tok_len, d_off, d_len, B,
+                              c.n_head, maxN, att_scale, st);
     gemm(m, st, m->ctxd.f(), d, m->W(p + "out.w").d, d, d, d, xd, d, m->W(p + "out.b").d, xd, d, nullptr, 0, ML, false);
   }
   dec_ffn("dec3.", c.dec_layers, xd, m->td.f());

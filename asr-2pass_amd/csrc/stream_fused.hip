@@ -433,11 +433,22 @@ __global__ __launch_bounds__(1024) void fused_gemv1t_kernel(
 // waves: every operand is requested at kernel start (Q / K fragments of the wave's 32-wide slice of d, the V rows of its 32-wide
 // slice of the output), scores = four partial 32 x 32 tiles on the fp32 MFMA summed through LDS, one softmax pass with 32 lanes per
 // query, P V as ceil(Lk / 2) MFMAs per wave.  Same arithmetic type as the general kernel (fp32 MFMA = fmaf chains, exp2).
+// Grid (head, window): with segment arrays (device: row offsets and lengths per window, as launch_attention takes them) a round of
+// connections is one launch of H x B small workgroups.
 __global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
                                                                const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
-                                                               int Lq, int Lk, float scale_log2e) {
+                                                               int Lq, int Lk, float scale_log2e, const int* __restrict__ q_off,
+                                                               const int* __restrict__ q_len, const int* __restrict__ kv_off,
+                                                               const int* __restrict__ kv_len) {
   __shared__ float sp[4][32][33];
   __shared__ float P[32][33];
+  if (q_off) {
+    const int b = blockIdx.y;
+    Lq = q_len[b]; Lk = kv_len[b];
+    if (Lq <= 0 || Lk <= 0) return;
+    Q += (size_t)q_off[b] * ldq; O += (size_t)q_off[b] * ldo;
+    K += (size_t)kv_off[b] * ldk; V += (size_t)kv_off[b] * ldv;
+  }
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -745,7 +756,17 @@ bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, c
   static const bool on = [] { const char* e = getenv("PFHIP_STREAM_WATT"); return !(e && e[0] == '0'); }();
   if (!on || Lq < 1 || Lq > 32 || Lk < 1 || Lk > 32 || H < 1) return false;
   hipLaunchKernelGGL(window_attention_kernel, dim3(H), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk,
-                     scale * 1.4426950408889634f);
+                     scale * 1.4426950408889634f, nullptr, nullptr, nullptr, nullptr);
+  return true;
+}
+// B windows in one launch: segment arrays on the device, max_q_len / max_kv_len their host-side maxima (both <= 32 or false)
+bool launch_window_attention_segments(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                                      const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                                      int max_q_len, int max_kv_len, float scale, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("PFHIP_STREAM_WATT"); return !(e && e[0] == '0'); }();
+  if (!on || B < 1 || H < 1 || max_q_len < 1 || max_q_len > 32 || max_kv_len < 1 || max_kv_len > 32) return false;
+  hipLaunchKernelGGL(window_attention_kernel, dim3(H, B), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, 0, 0,
+                     scale * 1.4426950408889634f, q_off, q_len, kv_off, kv_len);
   return true;
 }
 

@@ -759,7 +759,8 @@ static bool x6_enabled() {
 }
 bool gemm_x6_ln_ok(int M) {
   static const bool ln_on = [] { const char* e = getenv("PFHIP_GEMM_LN"); return !(e && e[0] == '0'); }();
-  return ln_on && x6_enabled() && ((M + kTileM - 1) / kTileM) * 4 >= 128;       // N = 512: four column tiles per row panel
+  // from the batch size at which the N = 512 launches (four column tiles per row panel) go to the BF16-split kernels at all
+  return ln_on && x6_enabled() && ((M + kTileM - 1) / kTileM) * 4 >= 48;
 }
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
@@ -767,8 +768,11 @@ void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, flo
   if (M <= 0 || N <= 0) return;
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
   const bool small_tile = !(K >= 1024 && tiles256 >= 180);
+  const int tiles128 = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
+  const bool half_tile = small_tile && tiles128 <= 160;       // as the default dispatch: 64-row tiles where 128-row ones leave CUs idle
   launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                         column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out, false, ln_colsum);
+                         column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out, half_tile,
+                         ln_colsum);
 }
 
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,

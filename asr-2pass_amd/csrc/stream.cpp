@@ -278,6 +278,8 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
                    const float* R1, int ldr1, const float* fv, int ldv, const float* fw, int rows, int N, int K, bool relu) {
     return Wd && pfhip::launch_fused_gemv_1trip(X, ldx, Wd, ldw, Cd, ldc, bias, colsum, 1e-12f, R1, ldr1, fv, ldv, fw, rows, N, K, relu, st);
   };
+  const bool fuse_ln_s = !lean && m->d_lnw_qkv != nullptr && pfhip::gemm_x6_ln_ok(M);
+  if (fuse_ln_s) HIP_TRY(m->lnstats.ensure((size_t)(M + 256) * 4 * 2 * 4));
   // ---- streaming encoder session (:448): SAN-M stack on the windows as given (no scale/PE inside) --------
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
@@ -316,15 +318,31 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
                 nullptr, M, d, c.ffn, false);
       continue;
     }
-    lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
-    gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
-         m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
+    // rounds of many connections (>= 1536 rows): the two LayerNorms of a layer folded into the GEMMs around them, as offline
+    // (pfhip.cpp enqueue_locked: row statistics from the producing epilogue, algebraic normalisation in the consumer's)
+    if (fuse_ln_s && !first)
+      pfhip::launch_gemm_f32_x6_ln(x, d, m->d_lnw_qkv + (size_t)i * 3 * d * d, d, m->qkv.f(), 3 * d, m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, 0,
+                                   nullptr, 0, M, 3 * d, d, false, m->lnstats.f(), 4, m->d_lns_qkv + (size_t)i * 3 * d, nullptr, st);
+    else {
+      lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
+      gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
+           m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
+    }
     pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, B, maxn, d, st);
     // windows of <= 32 rows: one small workgroup per (head, connection) instead of the long-sequence kernel
     if (!pfhip::launch_window_attention_segments(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
                                                  d_len, d_off, d_len, B, c.n_head, maxn, maxn, att_scale, st))
       pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
                               d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+    if (fuse_ln_s) {
+      pfhip::launch_gemm_f32_x6_ln(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d, first ? nullptr : x, d, M,
+                                   d, d, false, nullptr, 4, nullptr, m->lnstats.f(), st);
+      pfhip::launch_gemm_f32_x6_ln(x, d, m->d_lnw_ffn1 + (size_t)i * c.ffn * d, d, m->hbuf.f(), c.ffn, m->d_lnb_ffn1 + (size_t)i * c.ffn,
+                                   nullptr, 0, nullptr, 0, M, c.ffn, d, true, m->lnstats.f(), 4, m->d_lns_ffn1 + (size_t)i * c.ffn, nullptr, st);
+      pfhip::launch_gemm_f32_x6_ln(m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0, M, d, c.ffn,
+                                   false, nullptr, 4, nullptr, i + 1 < c.enc_layers ? m->lnstats.f() : nullptr, st);
+      continue;
+    }
     gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,
          first ? nullptr : x, d, M, false);
     lnorm(m, st, x, d, m->y.f(), d, p + "norm2", M, d, d);

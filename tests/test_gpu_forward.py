@@ -191,12 +191,14 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
     model.close()
 
 
-def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod):
-    """Batches of >= 4096 rows take the fused encoder path (pfhip.cpp `fuse_ln`): the GEMMs that write the residual stream leave
+@pytest.mark.parametrize("n_utts,check", [(36, (0, 13, 35)), (5, (0, 4))])
+def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod, n_utts, check):
+    """Batches of >= 1536 rows take the fused encoder path (pfhip.cpp `fuse_ln`): the GEMMs that write the residual stream leave
     per-tile row statistics, the GEMMs that read it normalise on load with gamma folded into their weights and beta into their
     bias.  Here gamma in [0.5, 1.5] and beta in [-0.5, 0.5] for every LayerNorm (the default synthetic weights keep them within
     5 % of 1 / 0), 36 x 30 s = 18000 encoder rows and > 4096 decoder rows (so the decoder's norm1 -> FFN1 and ffn_norm -> FFN2
-    folds run too), against the oracle's explicit two-pass LayerNorm."""
+    folds run too) and 5 x 30 s = 2500 rows (the 64-row tiles of the same kernels), against the oracle's explicit two-pass
+    LayerNorm."""
     cfg = weights_mod.small_config(enc_layers=4, dec_layers=2, vocab=700)
     man, blob = weights_mod.synth_weights(cfg, seed=77)
     rng = np.random.default_rng(5)
@@ -206,14 +208,17 @@ def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod
             blob[o:o + n] = (rng.uniform(0.5, 1.5, n) if name.endswith(".g") else rng.uniform(-0.5, 0.5, n)).astype(np.float32)
     model = pkg.ParaformerHip().InitAsr((man, blob))
     W = P.Weights(man, blob)
-    utts = [synth_pcm(i, 480000 - 1234 * (i % 9), rng) for i in range(36)]
+    utts = [synth_pcm(i, 480000 - 1234 * (i % 9), rng) for i in range(n_utts)]
     got = model.forward_ids(utts, want_logp=True)
-    assert int(sum(got["n_frames"])) >= 4096 and int(sum(got["n_fires"])) >= 4096
+    if n_utts == 36:
+        assert int(sum(got["n_frames"])) >= 4096 and int(sum(got["n_fires"])) >= 4096
+    else:
+        assert 1536 <= int(sum(got["n_frames"])) < 4096
     enc = model.get_tensor("enc", int(sum(got["n_frames"])) * 512).reshape(-1, 512)
     o = 0
     for i, u in enumerate(utts):
         T = int(got["n_frames"][i])
-        if i in (0, 13, 35):
+        if i in check:
             ref = P.forward_pcm(u, W)
             assert np.abs(enc[o:o + T] - ref["enc"]).max() < 2e-4, i
             assert int(got["token_num"][i]) == ref["token_num"]

@@ -213,7 +213,8 @@ bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, c
                              int H, float scale, hipStream_t s);
 bool launch_window_attention_segments(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                                       const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
-                                      int max_q_len, int max_kv_len, float scale, hipStream_t s);
+                                      int max_q_len, int max_kv_len, float scale, hipStream_t s, const float* fsmn_w = nullptr,
+                                      float* mem = nullptr, int ldmem = 0);
 // The window's attention AND the projection of its context by W [N, 512] (+bias, +R1, + the FSMN memory of fsmn_v) in one launch:
 // every workgroup redoes the attention and keeps the context in LDS (stream_fused.hip).  H = 4 heads of 128, Lq <= 20, Lk <= 32.
 bool launch_fused_att_out(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int Lq, int Lk, int H, float scale,

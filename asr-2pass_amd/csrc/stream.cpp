@@ -328,12 +328,15 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
       gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
            m->W(p + "qkv.b").d, nullptr, 0, nullptr, 0, M, false);
     }
-    pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, B, maxn, d, st);
-    // windows of <= 32 rows: one small workgroup per (head, connection) instead of the long-sequence kernel
+    // windows of <= 32 rows: one small workgroup per (head, connection) instead of the long-sequence kernel, the FSMN memory of V
+    // written by the same launch
     if (!pfhip::launch_window_attention_segments(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
-                                                 d_len, d_off, d_len, B, c.n_head, maxn, maxn, att_scale, st))
+                                                 d_len, d_off, d_len, B, c.n_head, maxn, maxn, att_scale, st, m->W(p + "fsmn.w").d,
+                                                 m->mem.f(), d)) {
+      pfhip::launch_fsmn(m->qkv.f() + 2 * d, 3 * d, m->W(p + "fsmn.w").d, nullptr, 0, m->mem.f(), d, d_off, d_len, B, maxn, d, st);
       pfhip::launch_attention(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, d_off,
                               d_len, d_off, d_len, B, c.n_head, maxn, att_scale, st);
+    }
     if (fuse_ln_s) {
       pfhip::launch_gemm_f32_x6_ln(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d, first ? nullptr : x, d, M,
                                    d, d, false, nullptr, 4, nullptr, m->lnstats.f(), st);

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
                                                                const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
                                                                int Lq, int Lk, float scale_log2e, const int* __restrict__ q_off,
                                                                const int* __restrict__ q_len, const int* __restrict__ kv_off,
-                                                               const int* __restrict__ kv_len) {
+                                                               const int* __restrict__ kv_len, const float* __restrict__ fsmn_w,
+                                                               float* __restrict__ mem, int ldmem) {
   __shared__ float sp[4][32][33];
   __shared__ float P[32][33];
   if (q_off) {
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
     if (Lq <= 0 || Lk <= 0) return;
     Q += (size_t)q_off[b] * ldq; O += (size_t)q_off[b] * ldo;
     K += (size_t)kv_off[b] * ldk; V += (size_t)kv_off[b] * ldv;
+    if (mem) mem += (size_t)kv_off[b] * ldmem;
   }
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -479,6 +481,36 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
   // D[i = query][j = key]: j = lane & 31, i = (e & 3) + 8 * (e >> 2) + 4 * hh
 #pragma unroll
   for (int e = 0; e < 16; ++e) sp[w][(e & 3) + 8 * (e >> 2) + 4 * hh][r] = acc[e];
+  // SAN-M memory block of the window (self-attention only: the V rows are the window's own): mem[t][c] = v[t][c] + sum_j
+  // w[c][j] v[t + j - 5][c], rows outside [0, Lk) zero — launch_fsmn's operation order.  This lane holds column c = h*128 + w*32 + r
+  // of the rows with its parity (vf[st] = row 2 st + hh); the other parity comes from lane ^ 32.
+  if (fsmn_w) {
+    const int c = h * 128 + w * 32 + r;
+    float wk[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) wk[j] = fsmn_w[(size_t)c * 11 + j];
+    float col[32];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const float other = __shfl_xor(vf[st], 32);
+      col[2 * st] = hh ? other : vf[st];
+      col[2 * st + 1] = hh ? vf[st] : other;
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int t = 2 * st + par;                        // both lanes walk all rows; each stores its own parity
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+          const int u = t + j - 5;
+          if (u >= 0 && u < 32) a += wk[j] * col[u];       // rows >= Lk were loaded as zero
+        }
+        if (par == hh && t < Lk) mem[(size_t)t * ldmem + c] = col[t] + a;
+      }
+    }
+  }
   __syncthreads();
   for (int row = tid >> 5; row < Lq; row += 8) {          // 32 lanes per query
     const int k = tid & 31;
@@ -756,17 +788,20 @@ bool launch_window_attention(const float* Q, int ldq, const float* K, int ldk, c
   static const bool on = [] { const char* e = getenv("PFHIP_STREAM_WATT"); return !(e && e[0] == '0'); }();
   if (!on || Lq < 1 || Lq > 32 || Lk < 1 || Lk > 32 || H < 1) return false;
   hipLaunchKernelGGL(window_attention_kernel, dim3(H), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk,
-                     scale * 1.4426950408889634f, nullptr, nullptr, nullptr, nullptr);
+                     scale * 1.4426950408889634f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   return true;
 }
-// B windows in one launch: segment arrays on the device, max_q_len / max_kv_len their host-side maxima (both <= 32 or false)
+// B windows in one launch: segment arrays on the device, max_q_len / max_kv_len their host-side maxima (both <= 32 or false).
+// fsmn_w != nullptr (self-attention: q segments == kv segments, V = H * 128 channels wide): the launch also writes the encoder
+// layer's FSMN memory of V into mem (what launch_fsmn computes) — one launch per layer less in a round of connections.
 bool launch_window_attention_segments(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                                       const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
-                                      int max_q_len, int max_kv_len, float scale, hipStream_t s) {
+                                      int max_q_len, int max_kv_len, float scale, hipStream_t s, const float* fsmn_w, float* mem,
+                                      int ldmem) {
   static const bool on = [] { const char* e = getenv("PFHIP_STREAM_WATT"); return !(e && e[0] == '0'); }();
   if (!on || B < 1 || H < 1 || max_q_len < 1 || max_q_len > 32 || max_kv_len < 1 || max_kv_len > 32) return false;
   hipLaunchKernelGGL(window_attention_kernel, dim3(H, B), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, 0, 0,
-                     scale * 1.4426950408889634f, q_off, q_len, kv_off, kv_len);
+                     scale * 1.4426950408889634f, q_off, q_len, kv_off, kv_len, fsmn_w, mem, ldmem);
   return true;
 }
 

@@ -724,14 +724,15 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
                               column_group_width(M, K, (N + kTileN - 1) / kTileN), s);
     return;
   }
-  // (tools/gemm_small_probe.py: between 48 and 160 tiles of 128 x 128 the half-height BF16-split kernel beats both the fp32-MFMA
+  // (tools/gemm_small_probe.py: between 48 and 128 tiles of 128 x 128 the half-height BF16-split kernel beats both the fp32-MFMA
   // 64-row kernel and the 128 x 128 BF16-split kernel by 15-25 % — 1-5 utterances of 30 s, rounds of 25-128 streaming connections)
   if (kind == 4 || kind == 5 || kind == 7 || (kind == 0 && x6_on && tiles >= 48)) {
     const bool small_tile = kind == 5 || kind == 7 || (kind == 0 && !(K >= 1024 && tiles256 >= 180));
-    // measured (tools/gemm_x6_probe.py SHAPES=dec, kinds 5 vs 7): the half-height tile wins only while the 128 x 128 grid
-    // leaves most CUs with a single workgroup (<= 160 tiles: 19.8 vs 23.9 us at M = 4000, N = K = 512); from 220 tiles on the
-    // taller tile is ahead again (28.3 vs 31.1 us at M = 7015)
-    const bool half_tile = kind == 7 || (kind == 0 && small_tile && tiles <= 160);
+    // measured (tools/gemm_mid_probe.py, kinds 5 vs 7, N = 512): the half-height tile wins while its own grid still fits one
+    // workgroup per CU (<= 128 tiles of 128 x 128 = 256 half tiles: 19.0 vs 22.1 us at M = 4000, K = 512; 61 vs 66 at K = 2048);
+    // at 160 tiles (316 half tiles: a second, mostly empty round) the taller tile is ahead again (23.2 vs 27.4, 72 vs 93 us at
+    // M = 5000), as at 220 (28.3 vs 31.9 at M = 7015)
+    const bool half_tile = kind == 7 || (kind == 0 && small_tile && tiles <= 128);
     launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
                            column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, nullptr, 0, nullptr, half_tile);
     return;
@@ -769,7 +770,7 @@ void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, flo
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
   const bool small_tile = !(K >= 1024 && tiles256 >= 180);
   const int tiles128 = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
-  const bool half_tile = small_tile && tiles128 <= 160;       // as the default dispatch: 64-row tiles where 128-row ones leave CUs idle
+  const bool half_tile = small_tile && tiles128 <= 128;       // as the default dispatch: 64-row tiles where 128-row ones leave CUs idle
   launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
                          column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out, half_tile,
                          ln_colsum);

@@ -264,3 +264,19 @@ def test_one_small_token_buffer_does_not_fail_the_other_connections(pkg, weights
     for s in streams:
         s.close()
     model.close()
+
+
+def test_full_size_stream_matches_oracle(pkg, weights_mod):
+    """BASELINE.json configs[2] at the model's real size: Paraformer-large-sized random-init weights (50 encoder / 16 decoder layers,
+    vocabulary 8404), one connection fed 600-ms chunks — the latency path with every window-sized launch shape of the deployed model
+    (one-trip GEMVs over K = 512 / 2048, the 16-layer K/V projection, the vocabulary projection) — against the streaming oracle call by
+    call: ids identical, window rows / encoder output / alphas / log-probs within the tolerances of the small-model tests above."""
+    cfg = dict(weights_mod.PARAFORMER_LARGE)
+    man, blob = weights_mod.synth_weights(cfg, seed=1234)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    W = P.Weights(man, blob)
+    rng = np.random.default_rng(21)
+    pcm = synth_pcm(9, 9600 * 5 + 3000, rng)
+    on = run_both(pkg, model, W, pcm, [(9600, False)] * 5 + [(3000, True)])
+    assert sum(len(c["ids"]) for c in on.chunk_log) > 0
+    model.close()

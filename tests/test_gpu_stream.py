@@ -280,3 +280,45 @@ def test_full_size_stream_matches_oracle(pkg, weights_mod):
     on = run_both(pkg, model, W, pcm, [(9600, False)] * 5 + [(3000, True)])
     assert sum(len(c["ids"]) for c in on.chunk_log) > 0
     model.close()
+
+
+def test_large_round_of_connections_with_strong_layernorm(pkg, weights_mod):
+    """A round of 90 connections is 1800 rows: the batched encoder takes the LayerNorm-folded GEMMs (>= 1536 rows: 64-row tiles of the
+    BF16-split kernels, row statistics from the producing epilogue), the (head, connection) window-attention launch that also writes
+    the FSMN memory, and the decoder's per-connection cached FSMN.  gamma in [0.5, 1.5], beta in [-0.5, 0.5] for every LayerNorm.
+    Three of the connections against the streaming oracle (ids identical, log-probs within 1e-3), all of them against the same
+    connection fed alone (ids identical) over three rounds, the last one final."""
+    cfg = weights_mod.small_config(enc_layers=3, dec_layers=2, vocab=600)
+    man, blob = weights_mod.synth_weights(cfg, seed=31)
+    rng = np.random.default_rng(6)
+    for name, t in man["tensors"].items():
+        if "norm" in name and (name.endswith(".g") or name.endswith(".b")):
+            o, n = t["offset"] // 4, int(np.prod(t["shape"]))
+            blob[o:o + n] = (rng.uniform(0.5, 1.5, n) if name.endswith(".g") else rng.uniform(-0.5, 0.5, n)).astype(np.float32)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    W = P.Weights(man, blob)
+    B, rounds = 90, 3
+    waves = [synth_pcm(200 + i, 9600 * rounds, rng) for i in range(B)]
+    streams = [pkg.ParaformerOnlineHip(model) for _ in range(B)]
+    got = [[] for _ in range(B)]
+    for k in range(rounds):
+        res = pkg.ParaformerOnlineHip.forward_batch(streams, [w[k * 9600:(k + 1) * 9600] for w in waves], [k == rounds - 1] * B)
+        for i, r in enumerate(res):
+            got[i] += r
+    for s in streams:
+        s.close()
+    assert sum(len(g) for g in got) > B
+    for i in range(B):
+        s = pkg.ParaformerOnlineHip(model)
+        ids = []
+        for k in range(rounds):
+            ids += s.Forward(waves[i][k * 9600:(k + 1) * 9600], input_finished=(k == rounds - 1))
+        s.close()
+        assert ids == got[i], i
+    for i in (0, 44, 89):
+        on = PO.ParaformerOnline(W)
+        ids = []
+        for k in range(rounds):
+            ids += on.Forward(waves[i][k * 9600:(k + 1) * 9600], k == rounds - 1)
+        assert ids == got[i], i
+    model.close()

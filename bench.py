@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-streaming", action="store_true", help="skip the C3 streaming block (rank 0, N = 1 only)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="batches in flight per GPU in the timed region behind `value` (model replicas on the device, one host thread and "
+                         "one stream each); 1 = back to back.  The back-to-back figures and the roofline are always measured too")
     args = ap.parse_args()
 
     import torch
@@ -185,8 +188,32 @@ def main():
         model.enqueue_device(d_pcm.data_ptr(), sample_off, n_samples, stream.cuda_stream)
         return model.fetch(args.batch, max_tokens)
 
+    # Several batches in flight (the reference's serving shape is concurrent decoder threads: funasr-wss-server.cpp:479-481,
+    # run_server_offline.sh:39).  One launch of this workload already fills the chip; what a second and third batch in flight buy is
+    # their matrix-core phases over another batch's bandwidth-bound ones (epilogues, FSMN prologue, the host round trip for the token
+    # counts): tools/two_batches_probe.py measured 41.0 -> 38.6 (2) -> 37.8 (3) -> 38.4 (4) ms per batch on one box.
+    n_fly = max(1, args.in_flight)
+    replicas = [model] + [pkg.ParaformerHip().InitAsr((man, blob), device=local_rank) for _ in range(n_fly - 1)]
+    rstreams = [stream] + [torch.cuda.Stream(device=local_rank) for _ in range(n_fly - 1)]
+
+    def run_replica(i, k):
+        for _ in range(k):
+            replicas[i].enqueue_device(d_pcm.data_ptr(), sample_off, n_samples, rstreams[i].cuda_stream)
+            replicas[i].fetch(args.batch, max_tokens)
+
+    def steps_in_flight(k):
+        import threading
+        share = [k // n_fly + (1 if i < k % n_fly else 0) for i in range(n_fly)]
+        th = [threading.Thread(target=run_replica, args=(i, share[i])) for i in range(n_fly) if share[i]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
     for _ in range(args.warmup):
         res = step()
+    if n_fly > 1:
+        steps_in_flight(max(args.warmup, n_fly))
     # HIP events around the launches of the dominant kernel class only (the fp32 GEMM): bracketing all ~1000
     # launches of a step costs ~6 % of the step, bracketing the 284 GEMMs ~1 %
     model.profile_enable(0 if args.no_profile else GEMM_ONLY_MASK)
@@ -213,6 +240,20 @@ def main():
         prof_all = model.profile_read(reset=True)
         model.profile_enable(0)
     dt = max_over_ranks(dt, dist, torch.device("cuda", local_rank))
+    dt_seq = dt
+    if n_fly > 1:       # the same K steps, n_fly of them in flight: this timed region is the one behind `value`
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps_in_flight(args.steps)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        dt = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+        for r_ in replicas[1:]:
+            r_.close()
     # the same K steps on the reference's own boundary: host float** buffers in (Model::Forward(float** din, ...), H2D inside
     # the timed region where paraformer-torch.cpp:355-358 has it), ids out — reported beside `value`, never as `value`
     for _ in range(min(args.warmup, 2)):
@@ -244,8 +285,15 @@ def main():
             "value_host_buffers": audio_per_step * args.steps / dt_host, "ms_per_step_host_buffers": 1e3 * dt_host / args.steps,
             "host_buffers_note": "same steps through pfhip_offline_forward(float** host pcm): the 61 MB H2D copy of the batch is "
                                  "inside the timed region (the reference's Model::Forward boundary); `value` has the PCM resident in HBM",
+            "value_one_in_flight": audio_per_step * args.steps / dt_seq, "ms_per_step_one_in_flight": 1e3 * dt_seq / args.steps,
+            "in_flight_note": f"`value` / `ms_per_step`: the K steps with {n_fly} batches in flight per GPU ({n_fly} model replicas on the "
+                              "device, one host thread and stream each — the reference serves with concurrent decoder threads); "
+                              "`*_one_in_flight`: the same K steps back to back on one replica, which is also the timed region the "
+                              "roofline's HIP events bracket (with several batches in flight a launch's event-to-event time is not "
+                              "its own) and the command behind profiles/ (`--in-flight 1`)",
             "config": {"workload": f"Paraformer-large offline, batch={args.batch} x {args.seconds} s synthetic 16 kHz "
                                    f"utterances per GPU (BASELINE.json configs[1])",
+                       "in_flight": n_fly,
                        "batch_per_gpu": args.batch, "utt_seconds": args.seconds, "lfr_frames_per_utt": int(res["n_frames"][0]),
                        "tokens_per_batch": tokens, "weights": "random-init Paraformer-large (seed 1234), fp32",
                        "parallelism": f"replicas x{world} (no collective)", "rtf": 1.0 / value},

@@ -47,3 +47,29 @@ for rep in range(3):
     torch.cuda.synchronize(); t_par = time.perf_counter() - t0
     print(f"{steps} batches back to back: {1e3 * t_seq / steps:.2f} ms per batch; {NR} in flight: {1e3 * t_par / (steps // NR * NR):.2f} ms per batch "
           f"({B * 30 * steps / t_seq:.0f} vs {B * 30 * (steps // NR * NR) / t_par:.0f} audio-s/s)", flush=True)
+
+# ---- the same through the product's router: ONE handle fronting NR replicas on this device (pfhip_create_group, what
+# PFHIP_DEVICES=0,0,0 builds), host float** buffers in (the reference's Model::Forward boundary), NR caller threads
+for m_ in models:
+    m_.close()
+grp = pkg.ParaformerHip().InitAsr((man, blob), devices=[0] * NR)
+one = pkg.ParaformerHip().InitAsr((man, blob))
+
+
+def run_host(model, k):
+    for _ in range(k):
+        model.forward_ids(utts, max_tokens=max_tokens)
+
+
+run_host(grp, NR); run_host(one, 2)
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run_host(one, steps)
+    torch.cuda.synchronize(); t_seq = time.perf_counter() - t0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    th = [threading.Thread(target=run_host, args=(grp, steps // NR)) for i in range(NR)]
+    for t in th: t.start()
+    for t in th: t.join()
+    torch.cuda.synchronize(); t_par = time.perf_counter() - t0
+    print(f"host buffers, one handle: back to back {1e3 * t_seq / steps:.2f} ms per batch; group of {NR} replicas, {NR} caller threads: "
+          f"{1e3 * t_par / (steps // NR * NR):.2f} ms per batch   replica calls {grp.group_stats()['calls']}", flush=True)

@@ -757,6 +757,7 @@ bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, f
   const int nf = K / (kWaves * ks * 4) >= 1 ? K / (kWaves * ks * 4) : 1;
   const int ki = ks * 4 * nf;
   if (K % ki || K / ki > kWaves || N % cw || (nf != 1 && nf != 2 && nf != 4)) return false;
+  if (64 * (K / ki) < (M <= 8 ? 8 : 20) * cw) return false;       // the lanes that finish the outputs must exist (tiny K)
   const dim3 grid(N / cw), block(64 * (K / ki));
 #define PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, RPL_, NF_)                                                                                      \
   hipLaunchKernelGGL((fused_gemv1t_kernel<LN_, FS_, CW_, CPL_, 4, RPL_, NF_>), grid, block, 0, s, X, ldx, W, ldw, C, ldc, bias, ln_colsum, eps, \

@@ -16,7 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 warm = 2
 man, blob = weights.synth_weights(dict(weights.PARAFORMER_LARGE), seed=1234)
-model = pkg.ParaformerHip().InitAsr((man, blob))
+NR = int(os.environ.get("REPLICAS", "1"))      # > 1: one handle fronting NR replicas on device 0; the batch call spans them concurrently
+model = pkg.ParaformerHip().InitAsr((man, blob), devices=[0] * NR) if NR > 1 else pkg.ParaformerHip().InitAsr((man, blob))
 rng = np.random.default_rng(20251114)
 streams = [pkg.ParaformerOnlineHip(model) for _ in range(B)]
 waves = [synth_pcm(1000 + i, 9600 * (rounds + warm), rng) for i in range(B)]
@@ -28,4 +29,4 @@ for k in range(warm + rounds):
     if k >= warm:
         tok += sum(len(r) for r in res)
 dt = (time.perf_counter() - t0) / rounds
-print(f"B {B} rounds {rounds} tokens {tok}: {1e3 * dt:.2f} ms per round = {B * 0.6 / dt:.0f} x real time")
+print(f"replicas {NR} B {B} rounds {rounds} tokens {tok}: {1e3 * dt:.2f} ms per round = {B * 0.6 / dt:.0f} x real time")

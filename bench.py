@@ -196,10 +196,12 @@ def main():
     replicas = [model] + [pkg.ParaformerHip().InitAsr((man, blob), device=local_rank) for _ in range(n_fly - 1)]
     rstreams = [stream] + [torch.cuda.Stream(device=local_rank) for _ in range(n_fly - 1)]
 
+    last_of_replica = [None] * n_fly
+
     def run_replica(i, k):
         for _ in range(k):
             replicas[i].enqueue_device(d_pcm.data_ptr(), sample_off, n_samples, rstreams[i].cuda_stream)
-            replicas[i].fetch(args.batch, max_tokens)
+            last_of_replica[i] = replicas[i].fetch(args.batch, max_tokens)
 
     def steps_in_flight(k):
         import threading
@@ -252,6 +254,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         dt = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+        for got in last_of_replica:        # every replica, under concurrency, returns what the back-to-back run returned
+            assert got is None or all(list(a) == list(b) for a, b in zip(got["ids"], res["ids"]))
         for r_ in replicas[1:]:
             r_.close()
     # the same K steps on the reference's own boundary: host float** buffers in (Model::Forward(float** din, ...), H2D inside

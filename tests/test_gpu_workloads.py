@@ -98,3 +98,37 @@ def test_c3_ten_minute_stream_one_connection(pkg, weights_mod):
     print(f"stream window rows: max err {worst_chunk:.2e} (p >= 9000: {worst_late:.2e}), {total_ids} ids over {n_chunks} chunks")
     hip.close()
     model.close()
+
+
+def test_c4_at_the_models_real_size(pkg, weights_mod):
+    """BASELINE.json configs[3] with the deployed model's dimensions: Paraformer-large-sized random-init weights (50 / 16 layers,
+    vocabulary 8404) carrying the contextual decoder and the timestamp head, a full batch of 32 ragged utterances (5-30 s) with
+    H = 16 hotwords through one forward; three of them against the oracle — ids, log-probs within 1e-3 (north_star), the upsampled
+    alphas / peaks and the character timestamps."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+    cfg = dict(weights_mod.PARAFORMER_LARGE, contextual=1, timestamp=1)
+    man, blob = weights_mod.synth_weights(cfg, seed=4040)
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    W = P.Weights(man, blob)
+    rng = np.random.default_rng(44)
+    lens = [int(v) for v in rng.integers(16000 * 5, 16000 * 30, 32)]
+    utts = [synth_pcm(100 + i, n, rng) for i, n in enumerate(lens)]
+    hot = [list(map(int, rng.integers(2, 8404, int(rng.integers(2, 7))))) for _ in range(16)]
+    hw = model.CompileHotwordEmbedding(hot)
+    got = model.forward_ids(utts, want_logp=True, hw_emb=hw, want_timestamps=True)
+    order = np.argsort(lens)
+    for b in (int(order[0]), int(order[16]), int(order[-1])):          # shortest, median, longest
+        ref = P.forward_pcm(utts[b], W, hw_emb=hw)
+        assert int(got["n_frames"][b]) == ref["enc"].shape[0]
+        assert int(got["token_num"][b]) == ref["token_num"]
+        assert list(got["ids"][b]) == list(ref["ids"]), b
+        assert np.abs(got["logp"][b] - ref["logp"]).max() < 1e-3, b
+        a_ref, p_ref = P.timestamp_head(ref["enc"], ref["token_num"], W)
+        a, p = got["us_alphas"][b], got["us_peaks"][b]
+        assert a.shape == a_ref.shape
+        assert np.abs(a - a_ref).max() < 1e-5 and np.abs(p - p_ref).max() < 2e-4, b
+        n_chars = max(0, ref["token_num"] - 1)
+        if n_chars:
+            assert TS.timestamp_onnx(a, p, n_chars) == TS.timestamp_onnx(a_ref, p_ref, n_chars), b
+    model.close()

@@ -191,7 +191,7 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
     model.close()
 
 
-@pytest.mark.parametrize("n_utts,check", [(36, (0, 13, 35)), (5, (0, 4))])
+@pytest.mark.parametrize("n_utts,check", [(36, (0, 13, 35)), (5, (0, 4)), (12, (0, 11))])
 def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod, n_utts, check):
     """Batches of >= 1536 rows take the fused encoder path (pfhip.cpp `fuse_ln`): the GEMMs that write the residual stream leave
     per-tile row statistics, the GEMMs that read it normalise on load with gamma folded into their weights and beta into their
@@ -212,6 +212,8 @@ def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod
     got = model.forward_ids(utts, want_logp=True)
     if n_utts == 36:
         assert int(sum(got["n_frames"])) >= 4096 and int(sum(got["n_fires"])) >= 4096
+    elif n_utts == 12:      # decoder rows between the two thresholds: its folded FFN2 (LayerNorm over 2048 columns) on 64-row tiles
+        assert int(sum(got["n_frames"])) >= 4096 and 1536 <= int(sum(got["n_fires"])) < 4096
     else:
         assert 1536 <= int(sum(got["n_frames"])) < 4096
     enc = model.get_tensor("enc", int(sum(got["n_frames"])) * 512).reshape(-1, 512)

@@ -8,6 +8,6 @@ for i in $(seq 1 "$N"); do
   for which in A B; do
     if [ $which = A ]; then export PFHIP_LIB=$A; else unset PFHIP_LIB; fi
     python3 bench.py --steps 20 --warmup 5 --no-streaming --no-cpu-baseline --no-profile 2>/dev/null |
-      python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$which', round(d['ms_per_step'],3), round(d['value'],1))"
+      python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$which', 'back to back', round(d['ms_per_step_one_in_flight'],3), 'ms;', d['config']['in_flight'], 'in flight', round(d['ms_per_step'],3), 'ms')"
   done
 done

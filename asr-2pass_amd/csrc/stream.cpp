@@ -359,8 +359,10 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
   float* col = m->qkv.f();
   float* po = m->ctx.f();
   pfhip::launch_im2col3(m->enc.f(), d, col, 3 * d, d_row_pos, d_row_len, M, d, st);
-  gemm(m, st, col, 3 * d, m->d_predconv, d, 3 * d, 3 * d, po, d, m->W("pred.conv.b").d,
-       c.pred_residual ? m->enc.f() : nullptr, d, nullptr, 0, M, true);
+  if (!lean || !gemv1(col, 3 * d, m->d_predconv, 3 * d, po, d, m->W("pred.conv.b").d, nullptr, c.pred_residual ? m->enc.f() : nullptr, d,
+                      nullptr, 0, nullptr, M, d, 3 * d, true))
+    gemm(m, st, col, 3 * d, m->d_predconv, d, 3 * d, 3 * d, po, d, m->W("pred.conv.b").d,
+         c.pred_residual ? m->enc.f() : nullptr, d, nullptr, 0, M, true);
   pfhip::launch_alpha(po, d, m->W("pred.out.w").d, m->W("pred.out.b").d, c.smooth_factor, c.noise_threshold,
                       m->alphas.f(), M, d, st);
   // ---- CifSearch (:270-345), one block per connection ---------------------------------------------------

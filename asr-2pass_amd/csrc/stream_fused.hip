@@ -756,7 +756,7 @@ bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, f
   const int ks = 64 / (cw / cpl * 4);
   const int nf = K / (kWaves * ks * 4) >= 1 ? K / (kWaves * ks * 4) : 1;
   const int ki = ks * 4 * nf;
-  if (K % ki || K / ki > kWaves || N % cw || (nf != 1 && nf != 2 && nf != 4)) return false;
+  if (K % ki || K / ki > kWaves || N % cw || nf < 1 || nf > 4) return false;
   if (64 * (K / ki) < (M <= 8 ? 8 : 20) * cw) return false;       // the lanes that finish the outputs must exist (tiny K)
   const dim3 grid(N / cw), block(64 * (K / ki));
 #define PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, RPL_, NF_)                                                                                      \
@@ -765,7 +765,7 @@ bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, f
 #define PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, NF_)                                   \
   do { if (M <= 8) PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, 2, NF_); else PFHIP_LAUNCH1T(LN_, FS_, CW_, CPL_, 5, NF_); } while (0)
 #define PFHIP_PICK_NF(LN_, FS_, CW_, CPL_)                                        \
-  do { if (nf == 1) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 1); else if (nf == 2) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 2); else PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 4); } while (0)
+  do { if (nf == 1) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 1); else if (nf == 2) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 2); else if (nf == 3) PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 3); else PFHIP_PICK_MR(LN_, FS_, CW_, CPL_, 4); } while (0)
 #define PFHIP_PICK_CW(LN_, FS_)                                                                       \
   do {                                                                                                \
     if (cpl == 1) { if (cw == 2) PFHIP_PICK_NF(LN_, FS_, 2, 1); else if (cw == 4) PFHIP_PICK_NF(LN_, FS_, 4, 1); else PFHIP_PICK_NF(LN_, FS_, 8, 1); } \

@@ -280,6 +280,35 @@ def main():
         torch.cuda.synchronize()
     dt_host = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
     assert all(list(a) == list(b) for a, b in zip(res_h["ids"], res["ids"]))
+    # ... and through the product's router: ONE handle fronting n_fly replicas on this device (pfhip_create_group — what
+    # PFHIP_DEVICES=d,d,d gives the unchanged server), n_fly caller threads as the server's decoder threads
+    dt_host_grp = None
+    if n_fly > 1:
+        try:
+            grp = pkg.ParaformerHip().InitAsr((man, blob), devices=[local_rank] * n_fly)
+            share = [args.steps // n_fly + (1 if i < args.steps % n_fly else 0) for i in range(n_fly)]
+
+            def host_calls(k):
+                for _ in range(k):
+                    grp.forward_ids(utts, max_tokens=max_tokens)
+            host_calls(n_fly)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=host_calls, args=(k,)) for k in share if k]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+            dt_host_grp = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+            grp.close()
+        except Exception as e:
+            print(f"bench.py: router leg skipped: {e}", file=sys.stderr)
 
     audio_per_step = world * args.batch * args.seconds
     value = audio_per_step * args.steps / dt
@@ -293,8 +322,11 @@ def main():
             "vs_baseline": None, "dtype": "f32 (operands split exactly into 3 bf16 planes, products on the BF16 matrix cores, fp32 accumulate)",
             "data": "synthetic",
             "value_host_buffers": audio_per_step * args.steps / dt_host, "ms_per_step_host_buffers": 1e3 * dt_host / args.steps,
+            "value_host_buffers_router": (audio_per_step * args.steps / dt_host_grp) if dt_host_grp else None,
             "host_buffers_note": "same steps through pfhip_offline_forward(float** host pcm): the 61 MB H2D copy of the batch is "
-                                 "inside the timed region (the reference's Model::Forward boundary); `value` has the PCM resident in HBM",
+                                 "inside the timed region (the reference's Model::Forward boundary); `value` has the PCM resident in HBM; "
+                                 "`value_host_buffers_router`: the same calls from in_flight threads on ONE handle that fronts in_flight "
+                                 "replicas on the device (pfhip_create_group / PFHIP_DEVICES=d,d,d: the unchanged server's decoder threads)",
             "value_one_in_flight": audio_per_step * args.steps / dt_seq, "ms_per_step_one_in_flight": 1e3 * dt_seq / args.steps,
             "in_flight_note": f"`value` / `ms_per_step`: the K steps with {n_fly} batches in flight per GPU ({n_fly} model replicas on the "
                               "device, one host thread and stream each — the reference serves with concurrent decoder threads); "

@@ -249,7 +249,9 @@ def main():
         model.profile_enable(0)
     dt = max_over_ranks(dt, dist, torch.device("cuda", local_rank))
     dt_seq = dt
-    if n_fly > 1:       # the same K steps, n_fly of them in flight: this timed region is the one behind `value`
+    # (the branch is taken by every rank or by none — args.in_flight, not the replica count a rank ended up with — so the
+    # barriers inside it cannot leave a rank behind)
+    if args.in_flight > 1:       # the same K steps, n_fly of them in flight: this timed region is the one behind `value`
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -283,7 +285,8 @@ def main():
     # ... and through the product's router: ONE handle fronting n_fly replicas on this device (pfhip_create_group — what
     # PFHIP_DEVICES=d,d,d gives the unchanged server), n_fly caller threads as the server's decoder threads
     dt_host_grp = None
-    if n_fly > 1:
+    if args.in_flight > 1:
+        local_dt = -1.0             # no collective inside the try: a rank that fails here must not strand the others
         try:
             grp = pkg.ParaformerHip().InitAsr((man, blob), devices=[local_rank] * n_fly)
             share = [args.steps // n_fly + (1 if i < args.steps % n_fly else 0) for i in range(n_fly)]
@@ -292,8 +295,6 @@ def main():
                 for _ in range(k):
                     grp.forward_ids(utts, max_tokens=max_tokens)
             host_calls(n_fly)
-            if dist is not None:
-                dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             th = [threading.Thread(target=host_calls, args=(k,)) for k in share if k]
@@ -302,13 +303,13 @@ def main():
             for t in th:
                 t.join()
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-                torch.cuda.synchronize()
-            dt_host_grp = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+            local_dt = time.perf_counter() - t0
             grp.close()
         except Exception as e:
             print(f"bench.py: router leg skipped: {e}", file=sys.stderr)
+        failed = max_over_ranks(1.0 if local_dt < 0 else 0.0, dist, torch.device("cuda", local_rank))
+        slowest = max_over_ranks(max(local_dt, 0.0), dist, torch.device("cuda", local_rank))
+        dt_host_grp = None if failed > 0 else slowest
 
     audio_per_step = world * args.batch * args.seconds
     value = audio_per_step * args.steps / dt

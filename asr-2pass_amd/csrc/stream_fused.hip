@@ -754,7 +754,9 @@ bool launch_fused_gemv_1trip(const float* X, int ldx, const float* W, int ldw, f
   const int cw = N <= 640 ? (K >= 2048 ? 2 : 4) : 8;
   if (cpl > cw || (cpl != 1 && cpl != 2 && cpl != 4)) return false;
   const int ks = 64 / (cw / cpl * 4);
-  const int nf = K / (kWaves * ks * 4) >= 1 ? K / (kWaves * ks * 4) : 1;
+  int nf = K / (kWaves * ks * 4) >= 1 ? K / (kWaves * ks * 4) : 1;
+  // N = 512, K = 512 (4-column patches): 8 waves with twice the k per lane beat 16 (4.45-4.66 vs 4.85 us: half the partial sums)
+  if (cw == 4 && 2 * nf <= 4 && K % (ks * 4 * 2 * nf) == 0 && 64 * (K / (ks * 4 * 2 * nf)) >= 20 * cw) nf *= 2;
   const int ki = ks * 4 * nf;
   if (K % ki || K / ki > kWaves || N % cw || nf < 1 || nf > 4) return false;
   if (64 * (K / ki) < (M <= 8 ? 8 : 20) * cw) return false;       // the lanes that finish the outputs must exist (tiny K)

@@ -26,8 +26,8 @@ KCLASS_NAMES = ["gemm", "attention", "layernorm", "fsmn", "fbank", "cif", "head"
 ABI_SYMBOLS = [
     "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_create_group", "pfhip_group_size", "pfhip_group_stats", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
-    "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch",
-    "pfhip_set_batching", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
+    "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch", "pfhip_offline_forward_resident",
+    "pfhip_set_batching", "pfhip_set_inflight", "pfhip_get_inflight", "pfhip_inflight_stats", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_debug_poke", "pfhip_profile_enable", "pfhip_profile_read",
     "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch", "pfhip_set_stream_batching",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
@@ -57,6 +57,11 @@ class _Out(ctypes.Structure):
         ("us_len", ctypes.POINTER(ctypes.c_int32)),
         ("max_us", ctypes.c_int32),
     ]
+
+
+class _SlotStats(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("context", ctypes.c_int32), ("forwards", ctypes.c_int64),
+                ("calls", ctypes.c_int64), ("utterances", ctypes.c_int64)]
 
 
 class _Profile(ctypes.Structure):
@@ -93,9 +98,13 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_offline_forward.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ci, ctypes.POINTER(_Out)]
     lib.pfhip_offline_enqueue.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ci), ci, vp]
     lib.pfhip_offline_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
+    lib.pfhip_offline_forward_resident.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ci), ci, ctypes.POINTER(_Out)]
     lib.pfhip_extract_feats.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, vp, ctypes.c_size_t, vp]
     lib.pfhip_get_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.pfhip_set_batching.argtypes = [vp, ci, ci]
+    lib.pfhip_set_inflight.argtypes = [vp, ci]
+    lib.pfhip_get_inflight.argtypes = [vp]
+    lib.pfhip_inflight_stats.argtypes = [vp, ctypes.POINTER(_SlotStats), ci, ctypes.POINTER(ci)]
     lib.pfhip_is_contextual.argtypes = [vp]
     lib.pfhip_hotword_embed.argtypes = [vp, vp, vp, ci, vp]
     lib.pfhip_set_hotwords.argtypes = [vp, vp, ci]
@@ -235,6 +244,21 @@ class ParaformerHip:
     def set_batching(self, wait_us, max_utterances=32):
         """Merge concurrent Forward callers into one packed device batch (pfhip_set_batching)."""
         _check(self._lib, self._lib.pfhip_set_batching(self._h, int(wait_us), int(max_utterances)))
+
+    def set_inflight(self, n):
+        """n execution contexts per device over the ONE weight set of this handle (pfhip_set_inflight)."""
+        _check(self._lib, self._lib.pfhip_set_inflight(self._h, int(n)))
+
+    def get_inflight(self):
+        return self._lib.pfhip_get_inflight(self._h)
+
+    def inflight_stats(self):
+        """Per execution slot: dict(device, context, forwards, calls, utterances) (pfhip_inflight_stats)."""
+        arr = (_SlotStats * 64)()
+        n = ctypes.c_int(0)
+        _check(self._lib, self._lib.pfhip_inflight_stats(self._h, arr, 64, ctypes.byref(n)))
+        return [dict(device=a.device, context=a.context, forwards=a.forwards, calls=a.calls, utterances=a.utterances)
+                for a in arr[:n.value]]
 
     def StartUtterance(self):  # paraformer.cpp:297-307: stateless
         pass
@@ -377,6 +401,27 @@ class ParaformerHip:
         out.logp = None
         out.max_tokens = max_tokens
         _check(self._lib, self._lib.pfhip_offline_fetch(self._h, ctypes.byref(out)))
+        return dict(token_num=tn, n_fires=nf, n_frames=fr, ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)])
+
+    def forward_resident(self, d_pcm_ptr: int, sample_off: np.ndarray, n_samples: np.ndarray, max_tokens: int):
+        """pfhip_offline_forward_resident: PCM already in HBM, routed over the handle's execution contexts like Forward."""
+        B = len(n_samples)
+        so = np.ascontiguousarray(sample_off, np.int64)
+        ns = np.ascontiguousarray(n_samples, np.int32)
+        ids = np.zeros((B, max_tokens), np.int32)
+        tn = np.zeros(B, np.int32)
+        nf = np.zeros(B, np.int32)
+        fr = np.zeros(B, np.int32)
+        out = _Out()
+        out.token_ids = ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.token_num = tn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.n_fires = nf.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.n_frames = fr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out.logp = None
+        out.max_tokens = max_tokens
+        _check(self._lib, self._lib.pfhip_offline_forward_resident(
+            self._h, ctypes.c_void_p(d_pcm_ptr), so.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            ns.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), B, ctypes.byref(out)))
         return dict(token_num=tn, n_fires=nf, n_frames=fr, ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)])
 
     def profile_enable(self, on=True):

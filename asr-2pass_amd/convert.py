@@ -2,13 +2,21 @@
 
 The reference server loads `model.onnx` + `am.mvn` + `config.yaml` from a ModelScope directory
 (onnxruntime/src/paraformer.cpp:21-53, websocket/bin/funasr-wss-server.cpp:203-320).  The same directories ship the
-PyTorch checkpoint the ONNX file was exported from (`model.pt` / `model.pb`); this module maps ITS state_dict to the
-container of `weights.py`.  Tensor names follow UPSTREAM FunASR (funasr/models/{sanm,paraformer,fsmn_vad_streaming,
-ct_transformer}); none of those files is available offline, so the mapping is checked only for self-consistency
-(tests/test_convert.py round-trips synthetic weights through the upstream naming) — first contact with real files
-is the f2 milestone that turns "parity unpinned" into token-for-token evidence.
+PyTorch checkpoint the ONNX file was exported from (`model.pt` / `model.pb`).  This module maps either to the container of
+`weights.py`:
 
-Checkpoints are read with `torch.load(..., weights_only=True)` only.
+  * `state_from_onnx_dir(dir)`: the reference's OWN file contract (onnxruntime/include/com-define.h:52-88) — `model.onnx`
+    (or `model_quant.onnx`, dequantised) [+ `decoder.onnx` for the online model, + `model_eb.onnx` for the hotword embedder],
+    read by the dependency-free protobuf reader `onnx_reader.py`; anonymous MatMul weights are named after their layer and
+    transposed back to torch layout, LSTM gate blocks re-ordered (ONNX i,o,f,c -> torch i,f,g,o);
+  * `load_state_dict(model.pt)`: the checkpoint, `torch.load(..., weights_only=True)` only.
+
+Tensor names follow UPSTREAM FunASR (funasr/models/{sanm,paraformer,contextual_paraformer,bicif_paraformer,
+fsmn_vad_streaming,ct_transformer}), written down from memory: none of those files is available offline, so the mapping is
+checked for self-consistency only (tests/test_convert.py round-trips synthetic weights through the upstream naming, and
+through a synthetic ONNX file for the directory path; the ONNX READER itself is tested on the real .onnx files the reference
+ships under utils/DNSMOS).  First contact with real Paraformer files is the milestone that turns "parity unpinned" into
+token-for-token evidence.
 """
 from __future__ import annotations
 
@@ -101,6 +109,27 @@ def paraformer_name_map(cfg):
     lin("dec3.ffn2", "decoder.decoders3.0.feed_forward.w_2", bias=False)
     ln("dec.after_norm", "decoder.after_norm")
     lin("dec.out", "decoder.output_layer")
+    if cfg.get("timestamp", 0):           # CifPredictorV3 (bicif_paraformer): ConvTranspose1d -> BLSTM -> Linear(2d, 1)
+        m["pred.up.w"], m["pred.up.b"] = "predictor.upsample_cnn.weight", "predictor.upsample_cnn.bias"
+        for sfx, tsfx in (("", ""), ("_r", "_reverse")):
+            m[f"pred.blstm.w_ih{sfx}"] = f"predictor.blstm.weight_ih_l0{tsfx}"
+            m[f"pred.blstm.w_hh{sfx}"] = f"predictor.blstm.weight_hh_l0{tsfx}"
+            m[f"pred.blstm.b_ih{sfx}"] = f"predictor.blstm.bias_ih_l0{tsfx}"
+            m[f"pred.blstm.b_hh{sfx}"] = f"predictor.blstm.bias_hh_l0{tsfx}"
+        lin("pred.out2", "predictor.cif_output2")
+    if cfg.get("contextual", 0):          # ContextualParaformer: the last attention layer is `last_decoder`, + bias decoder
+        last = cfg["dec_layers"] - 1
+        for k in list(m):
+            if k.startswith(f"dec.{last}."):
+                m[k] = m[k].replace(f"decoder.decoders.{last}.", "decoder.last_decoder.")
+        m["bias.embed.w"] = "bias_embed.weight"
+        for a, b in (("w_ih", "weight_ih_l0"), ("w_hh", "weight_hh_l0"), ("b_ih", "bias_ih_l0"), ("b_hh", "bias_hh_l0")):
+            m["bias.lstm." + a] = "bias_encoder." + b
+        ln("bias.dec.norm3", "decoder.bias_decoder.norm3")
+        lin("bias.dec.q", "decoder.bias_decoder.src_attn.linear_q")
+        lin("bias.dec.kv", "decoder.bias_decoder.src_attn.linear_k_v")
+        lin("bias.dec.out", "decoder.bias_decoder.src_attn.linear_out")
+        m["bias.out.w"] = "decoder.bias_output.weight"            # Conv1d(2d, d, 1, bias=False): [d, 2d, 1]
     return m
 
 
@@ -183,6 +212,70 @@ def convert_punc(state, cfg=None):
     cfg["n_punc"] = int(state[nm["out.w"]].shape[0])
     tensors, blob, total = _fill(Wt.punc_tensor_specs(cfg), nm, state, {})
     return {"config": cfg, "tensors": tensors, "total_bytes": total}, blob
+
+
+def state_from_onnx_dir(src, quantized=False):
+    """{torch-style key: ndarray} from a model directory laid out as the reference reads it (com-define.h:52-88;
+    paraformer.cpp:39-46 offline, :92-121 online encoder + decoder, :178-186 hotword embedder): model.onnx or model_quant.onnx,
+    plus decoder.onnx / decoder_quant.onnx and model_eb.onnx / model_eb_quant.onnx when present.  Later files win on a clash."""
+    import os
+    from . import onnx_reader as R
+    sfx = "_quant.onnx" if quantized else ".onnx"
+    main = os.path.join(src, "model" + sfx)
+    if not os.path.exists(main):
+        raise FileNotFoundError(main)
+    state, files = {}, []
+    for stem in ("model", "decoder", "model_eb"):
+        p = os.path.join(src, stem + sfx)
+        if not os.path.exists(p):
+            continue
+        m = R.read_model(p)
+        if m.external:
+            raise ValueError(f"{p}: {len(m.external)} initializers live in external data files (not supported)")
+        bad = R.check_closed(m)
+        if bad:
+            raise ValueError(f"{p}: graph is not closed over its initializers, e.g. {bad[:3]}")
+        state.update(R.torch_style_state(m))
+        files.append(p)
+    return state, files
+
+
+def detect_heads(state):
+    """contextual / timestamp flags from the tensors that are there (config.yaml names the model class, the weights decide)."""
+    return dict(contextual=int("decoder.bias_output.weight" in state or "bias_embed.weight" in state),
+                timestamp=int("predictor.upsample_cnn.weight" in state))
+
+
+def convert_model_dir(kind, src, prefer="auto", quantized=False):
+    """kind in {asr, vad, punc}; src = a model directory as the reference's server receives it (--model-dir / --vad-dir /
+    --punc-dir: model.onnx [+ decoder.onnx, model_eb.onnx], am.mvn / vad.mvn, config.yaml / vad.yaml / punc.yaml, tokens.json).
+    prefer: "onnx", "pt" or "auto" (ONNX when present).  Returns (manifest, blob, source files)."""
+    import os
+    import yaml
+    has_onnx = os.path.exists(os.path.join(src, "model_quant.onnx" if quantized else "model.onnx"))
+    if prefer == "onnx" or (prefer == "auto" and has_onnx):
+        state, files = state_from_onnx_dir(src, quantized)
+    else:
+        pt = next((os.path.join(src, n) for n in ("model.pt", "model.pb") if os.path.exists(os.path.join(src, n))), None)
+        if pt is None:
+            raise FileNotFoundError(f"{src}: neither model.onnx nor model.pt")
+        state, files = load_state_dict(pt), [pt]
+    if kind == "punc":
+        man, blob = convert_punc(state)
+        return man, blob, files
+    mvn = next((os.path.join(src, n) for n in (("vad.mvn", "am.mvn") if kind == "vad" else ("am.mvn",)) if os.path.exists(os.path.join(src, n))), None)
+    if mvn is None:
+        raise FileNotFoundError(f"{src}: am.mvn")
+    shift, rescale = parse_am_mvn(open(mvn).read())
+    if kind == "vad":
+        man, blob = convert_vad(state, shift, rescale)
+        return man, blob, files + [mvn]
+    ypath = os.path.join(src, "config.yaml")
+    with open(ypath) as f:
+        cfg = config_from_yaml(yaml.safe_load(f))
+    cfg.update(detect_heads(state))
+    man, blob = convert_paraformer(state, cfg, shift, rescale)
+    return man, blob, files + [mvn, ypath]
 
 
 def load_state_dict(path):

@@ -719,11 +719,6 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
   // fill the chip (FFN2 at full batch: 201 vs 194 TF).  PFHIP_GEMM_X6=0 turns the path off.
   static const bool x6_on = [] { const char* e = getenv("PFHIP_GEMM_X6"); return !(e && e[0] == '0'); }();
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
-  if (kind == 6) {
-    launch_gemm_f32_bf16x6_v2(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                              column_group_width(M, K, (N + kTileN - 1) / kTileN), s);
-    return;
-  }
   // (tools/gemm_small_probe.py: between 48 and 128 tiles of 128 x 128 the half-height BF16-split kernel beats both the fp32-MFMA
   // 64-row kernel and the 128 x 128 BF16-split kernel by 15-25 % — 1-5 utterances of 30 s, rounds of 25-128 streaming connections)
   if (kind == 4 || kind == 5 || kind == 7 || (kind == 0 && x6_on && tiles >= 48)) {

@@ -253,8 +253,14 @@ PuncModelHipBase* CreatePuncModelHip(const std::string& punc_dir, int thread_num
   }
   CTTransformerHip* m = allow_online && punc_dir.find("realtime") != std::string::npos ? new CTTransformerOnlineHip() : new CTTransformerHip();
   m->InitPunc(blob, man, tok, thread_num);
-  // one AddPunc per handler thread, each a few Infer calls: merged into packed device passes
-  if (thread_num > 1) pfhip_set_punc_batching(m->Handle(), 300, 128);
+  // One AddPunc per handler thread, each a few Infer calls: merged into packed device passes.  `thread_num` is the server's
+  // --model-thread-num (onnxruntime intra-op threads, default 1: funasr-wss-server.cpp:105-106), NOT the number of handler
+  // threads, so merging does not depend on it: a caller that finds the model idle runs at once, company queues behind it.
+  {
+    const char* e = std::getenv("PFHIP_PUNC_WAIT_US");
+    const int w = e ? std::atoi(e) : 300;
+    if (w > 0) pfhip_set_punc_batching(m->Handle(), w, 128);
+  }
   return m;
 }
 

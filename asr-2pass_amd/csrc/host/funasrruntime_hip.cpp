@@ -200,6 +200,7 @@ void FunASRFreeResult(FUNASR_RESULT result) { delete static_cast<RecogResult*>(r
 void FunOfflineUninit(FUNASR_HANDLE handle) { delete static_cast<OfflineStreamHip*>(handle); }
 const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->seg_ids; }
 const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->segs; }
+pfhip_model* FunOfflineGetAsrHandle(FUNASR_HANDLE handle) { return handle ? static_cast<OfflineStreamHip*>(handle)->asr.Handle() : nullptr; }
 
 
 // ---- 2-pass --------------------------------------------------------------------------------------------------------------
@@ -237,13 +238,15 @@ FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int t
   ts->vad.InitVad(model_path[VAD_DIR] + "/vad.pfhip.bin", "", model_path[VAD_DIR] + "/vad.pfhip.json", thread_num);   // exits on failure
   if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
     ts->punc_online.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, true));   // realtime or offline class
-  // one handler thread per connection in the server: merge their concurrent device calls into batched passes
-  if (thread_num > 1) {
-    auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+  // One handler thread per connection in the server: their concurrent device calls are merged into batched passes.  Not keyed
+  // on `thread_num`: that is --model-thread-num (onnxruntime intra-op threads, default 1: funasr-wss-server-2pass.cpp:110,569;
+  // websocket-server-2pass.cpp:629), not the number of handler threads.  A leader stops waiting as soon as every open
+  // connection has queued, so a lone connection pays nothing.  0 in a *_WAIT_US knob switches a queue off.  (The 2nd-pass
+  // model's queue and contexts are set up by ParaformerHip::InitAsr.)
+  {
+    auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
     pfhip_set_stream_batching(ts->asr_online.Handle(), knob("PFHIP_STREAM_WAIT_US", 3000), knob("PFHIP_STREAM_MAX", 128));
     pfhip_set_vad_stream_batching(ts->vad.Handle(), knob("PFHIP_VAD_WAIT_US", 1000), knob("PFHIP_VAD_MAX", 256));
-    if (std::getenv("PFHIP_OFFLINE_WAIT_US"))
-      pfhip_set_batching(ts->asr.Handle(), knob("PFHIP_OFFLINE_WAIT_US", 3000), knob("PFHIP_OFFLINE_MAX", 96));
   }
   return ts.release();
 }

@@ -71,3 +71,6 @@ void FunTpassUninit(FUNASR_HANDLE handle);
 // Inspection for tests: token ids per VAD segment in time order and the segments (samples) of the last result.
 const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result);
 const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result);
+// ... and the C-ABI handle of the offline acoustic model behind a FunOfflineInit handle (pfhip_inflight_stats in the harnesses)
+struct pfhip_model;
+pfhip_model* FunOfflineGetAsrHandle(FUNASR_HANDLE handle);

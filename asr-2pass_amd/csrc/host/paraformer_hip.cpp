@@ -44,9 +44,18 @@ void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_c
     std::fprintf(stderr, "Error when load am hip model: %s\n", pfhip_last_error());
     std::exit(-1);
   }
-  // thread_num = the decoder threads that will share this handle (funasr-wss-server.cpp:479-481): the reference gives
-  // each its own intra-op thread; here their concurrent Forward calls are merged into packed launches instead
-  if (thread_num > 1) pfhip_set_batching(handle_, 3000, 96);   // 96 merged utterances: +16 % over 32 on the long-audio flow
+  // `thread_num` is the server's --model-thread-num — onnxruntime intra-op threads, default 1 (funasr-wss-server.cpp:105-106,
+  // 452,511; websocket-server.cpp:433; used at paraformer.cpp:35) — NOT the number of decoder threads that share this handle
+  // (--decoder-thread-num, 8, or 16 in run_server_offline.sh:39).  It has no meaning here.  What the decoder threads get,
+  // whatever the flag says: their concurrent Forward calls are merged into packed launches (a lone caller never waits:
+  // pfhip_set_batching) and dealt to PFHIP_INFLIGHT execution contexts over the one weight set.
+  (void)thread_num;
+  auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
+  const int inflight = knob("PFHIP_INFLIGHT", 3);
+  if (inflight > 1 && pfhip_set_inflight(handle_, inflight) != PFHIP_OK)
+    std::fprintf(stderr, "ParaformerHip::InitAsr: %s (one forward at a time)\n", pfhip_last_error());
+  const int wait_us = knob("PFHIP_OFFLINE_WAIT_US", 3000);     // 0 = no merging
+  if (wait_us > 0) pfhip_set_batching(handle_, wait_us, knob("PFHIP_OFFLINE_MAX", 96));   // 96 merged utterances: +16 % over 32 on the long-audio flow
   if (!token_file.empty()) {                                   // paraformer.cpp:47-48
     delete vocab;
 #ifdef PFHIP_WITH_FUNASR

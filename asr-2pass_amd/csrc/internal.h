@@ -171,8 +171,10 @@ struct pfhip_model {
   int64_t* m_sample_off = nullptr;
   int *m_tok_off = nullptr, *m_tok_len = nullptr, *m_src_row = nullptr, *m_hw_off = nullptr, *m_hw_len = nullptr;
 
-  // cross-request batching (pfhip_set_batching): callers queue here, one of them leads a merged forward (merge_queue.h)
-  pfhip_detail::MergeQueue<BatchReq> bq;
+  // cross-request batching (pfhip_set_batching): callers queue at the handle they hold (ONE queue for every execution slot of
+  // the handle: contexts on this device, replicas on other devices); the caller at the front leads a merged forward on an idle
+  // slot while the next one already gathers the next batch (merge_queue.h PoolQueue)
+  pfhip_detail::PoolQueue<BatchReq, pfhip_model> bq;
   int batch_wait_us = 0, batch_max_utts = 32;
   // the same for streaming calls: concurrent pfhip_stream_forward callers (one thread per connection) are merged
   pfhip_detail::MergeQueue<StreamReq> sq;
@@ -191,30 +193,24 @@ struct pfhip_model {
   // models on the other devices of PFHIP_DEVICES / pfhip_create_group.  Offline calls go to the replica with the fewest calls
   // in flight, a new stream to the one with the fewest open streams (a connection stays on its device for life).
   std::vector<pfhip_model*> replicas;
-  pfhip_model* group_head = nullptr;        // replica -> the handle the caller holds (nullptr on the head itself)
+  pfhip_model* group_head = nullptr;        // replica / context -> the handle the caller holds (nullptr on the head itself)
   std::atomic<int> inflight{0};
-  std::atomic<int64_t> served_calls{0}, served_utts{0};
+  std::atomic<int64_t> served_calls{0}, served_utts{0}, served_forwards{0};
   std::atomic<unsigned> rr{0};
+  // Execution contexts (pfhip_set_inflight / PFHIP_INFLIGHT): further pfhip_model objects on THIS device that borrow every
+  // weight pointer of `weights_of` (the blob, the repacks, the LayerNorm-folded copies, the front-end tables) and own only a
+  // workspace, streams and events — the reference's one shared Ort::Session under many decoder threads (paraformer.cpp:35-41,541).
+  std::vector<pfhip_model*> contexts;       // on a device replica: its extra contexts (the replica itself is context 0)
+  pfhip_model* weights_of = nullptr;        // on a context: whose weights it borrows
+  int ctx_index = 0;
+  int ctx_limit = 1;                        // on the head: contexts per device that take calls (pfhip_set_inflight)
+  std::vector<pfhip_model*> slots;          // on the head: every execution slot of the handle, device-major round order; guarded by bq.mu
+  std::vector<float> hw_host;               // on the head: the resident hotword set (pfhip_set_hotwords), for contexts created later
 
   const Tensor& W(const std::string& n) const { return t.at(n); }
 };
 
 namespace pfhip_detail {
-// least-loaded replica of the group `m` heads (m itself when it has none); ties go round-robin
-inline pfhip_model* route_offline(pfhip_model* m) {
-  if (m->replicas.empty()) return m;
-  const size_t n = m->replicas.size() + 1;
-  const unsigned start = m->rr.fetch_add(1);
-  pfhip_model* best = nullptr;
-  int best_load = 0;
-  for (size_t k = 0; k < n; ++k) {
-    const size_t i = (start + k) % n;
-    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
-    const int load = r->inflight.load();
-    if (!best || load < best_load) { best = r; best_load = load; }
-  }
-  return best;
-}
 inline pfhip_model* route_stream(pfhip_model* m) {
   pfhip_model* best = m;
   for (pfhip_model* r : m->replicas)

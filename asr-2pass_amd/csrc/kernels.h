@@ -68,9 +68,6 @@ bool gemm_x6_ln_ok(int M);
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
                            const float* ln_colsum, float* stats_out, hipStream_t s);
-// the same arithmetic on v_mfma_f32_16x16x32_bf16 with K-concatenated planes (gemm_x6v2.hip): 128 x 128 tile, 4 waves
-void launch_gemm_f32_bf16x6_v2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
-                               int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s);
 void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                           int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, bool guard, int kind,
                           hipStream_t s);

@@ -108,6 +108,8 @@ pfhip_status build_frontend_tables(int n_mels, int sample_rate, FrontendTables* 
 namespace {
 using namespace pfhip_detail;
 
+pfhip_status create_streams(pfhip_model* m);
+
 pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
                          pfhip_model** out) {
   if (!blob || !manifest_json || !out) return fail(PFHIP_ERR_ARG, "null argument");
@@ -363,12 +365,48 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     for (int i = 0; i < half; ++i) inv[i] = (float)exp((double)(i * scale));
     if ((st = upload(&m->d_inv_ts, inv))) return st;
   }
+  {
+    pfhip_status st = create_streams(m.get());
+    if (st) return st;
+  }
+  for (auto& kv : m->t) kv.second.h = nullptr;
+  *out = m.release();
+  return PFHIP_OK;
+}
+
+// every device pointer of a model that is read-only after build_model: what an execution context borrows and only the owner frees
+#define PFHIP_WEIGHT_PTRS(X)                                                                                                  \
+  X(d_blob) X(d_w0qkv) X(d_predconv) X(d_vocab_bias) X(d_kv_all_w) X(d_kv_all_b) X(d_lnw_qkv) X(d_lnb_qkv) X(d_lnw_ffn1)     \
+  X(d_lnb_ffn1) X(d_lns_qkv) X(d_lns_ffn1) X(d_dlnw1) X(d_dlnb1) X(d_dlns1) X(d_dlnw2) X(d_dlnb2) X(d_dlns2) X(d_dlnw3)        \
+  X(d_dlnb3) X(d_dlns3) X(d_up_w) X(d_up_b) X(d_wih) X(d_bih) X(d_whh) X(d_window) X(d_tw) X(d_mel_off) X(d_mel_size)         \
+  X(d_mel_w) X(d_inv_ts)
+
+pfhip_status create_streams(pfhip_model* m) {
   HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_enc_ready, hipEventDisableTiming));
-  m->ev_kv.resize((size_t)c.dec_layers, nullptr);
+  m->ev_kv.resize((size_t)m->cfg.dec_layers, nullptr);
   for (auto& e : m->ev_kv) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto& kv : m->t) kv.second.h = nullptr;
+  return PFHIP_OK;
+}
+
+// An execution context on `owner`'s device: the reference's decoder threads share ONE session (paraformer.cpp:35-41,541); here
+// they share one weight set, and what a forward needs for itself — workspace, streams, events, the state of its last batch —
+// is a context.  Costs a few KB until its first forward sizes the workspace.
+pfhip_status build_context(pfhip_model* owner, pfhip_model** out) {
+  HIP_TRY(hipSetDevice(owner->device));
+  std::unique_ptr<pfhip_model> m(new pfhip_model);
+  m->device = owner->device;
+  m->cfg = owner->cfg;
+  m->feat_dim = owner->feat_dim; m->feat_pad = owner->feat_pad; m->vocab_pad = owner->vocab_pad;
+  m->t = owner->t;
+  m->out2_b = owner->out2_b;
+#define X(f) m->f = owner->f;
+  PFHIP_WEIGHT_PTRS(X)
+#undef X
+  m->weights_of = owner;
+  pfhip_status st = create_streams(m.get());
+  if (st) { pfhip_destroy(m.release()); return st; }
   *out = m.release();
   return PFHIP_OK;
 }
@@ -785,6 +823,10 @@ pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
     HIP_TRY(m->ts_cst.ensure((size_t)2 * 32 * 512 * 4));
     bool stepwise = force_stepwise;
     if (!stepwise) {
+      // the persistent kernel wants the 32 blocks of a direction co-resident on one XCD: two contexts of a device must not run
+      // it at the same time (they would time each other out into the per-step form) — one at a time per device
+      static std::mutex blstm_mu[64];
+      std::lock_guard<std::mutex> bl(blstm_mu[m->device & 63]);
       pfhip_status st = recurrence(false);
       if (st) return st;
       unsigned flag = 0;
@@ -912,6 +954,8 @@ extern "C" {
 
 const char* pfhip_last_error(void) { return g_err.c_str(); }
 
+static pfhip_status apply_env_inflight(pfhip_model** out);
+
 pfhip_status pfhip_create_group(const void* blob, size_t blob_bytes, const char* manifest_json, const int* devices, int n_devices,
                                 pfhip_model** out) {
   g_err.clear();
@@ -932,7 +976,7 @@ pfhip_status pfhip_create_group(const void* blob, size_t blob_bytes, const char*
     return fail(PFHIP_ERR_FORMAT, e.what());
   }
   *out = head;
-  return PFHIP_OK;
+  return apply_env_inflight(out);
 }
 
 // PFHIP_DEVICES="0,1,2,..." turns every model created through pfhip_create / pfhip_create_from_memory into a group with one
@@ -954,13 +998,26 @@ static bool env_devices(std::vector<int>& devs) {
   return !devs.empty();
 }
 
+// PFHIP_INFLIGHT=n: every handle is created with n execution contexts per device (pfhip_set_inflight)
+static pfhip_status apply_env_inflight(pfhip_model** out) {
+  const char* e = std::getenv("PFHIP_INFLIGHT");
+  if (!e || !*e) return PFHIP_OK;
+  const int n = std::atoi(e);
+  if (n < 1 || n > 16) return PFHIP_OK;
+  const pfhip_status st = pfhip_set_inflight(*out, n);
+  if (st) { const std::string why = g_err; pfhip_destroy(*out); *out = nullptr; g_err = why; }
+  return st;
+}
+
 pfhip_status pfhip_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
                                       pfhip_model** out) {
   g_err.clear();
   std::vector<int> devs;
   if (env_devices(devs)) return pfhip_create_group(blob, blob_bytes, manifest_json, devs.data(), (int)devs.size(), out);
-  try { return build_model(blob, blob_bytes, manifest_json, device, out); }
-  catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
+  try {
+    const pfhip_status st = build_model(blob, blob_bytes, manifest_json, device, out);
+    return st ? st : apply_env_inflight(out);
+  } catch (const std::exception& e) { return fail(PFHIP_ERR_FORMAT, e.what()); }
 }
 
 int pfhip_group_size(const pfhip_model* m) { return m ? 1 + (int)m->replicas.size() : 0; }
@@ -971,8 +1028,10 @@ pfhip_status pfhip_group_stats(pfhip_model* m, int* devices, int64_t* calls, int
   for (int i = 0; i <= (int)m->replicas.size(); ++i) {
     const pfhip_model* r = i == 0 ? m : m->replicas[(size_t)i - 1];
     if (devices) devices[i] = r->device;
-    if (calls) calls[i] = r->served_calls.load();
-    if (utterances) utterances[i] = r->served_utts.load();
+    int64_t nc = r->served_calls.load(), nu = r->served_utts.load();
+    for (const pfhip_model* cx : r->contexts) { nc += cx->served_calls.load(); nu += cx->served_utts.load(); }
+    if (calls) calls[i] = nc;
+    if (utterances) utterances[i] = nu;
     if (open_streams) open_streams[i] = r->live_streams.load();
   }
   return PFHIP_OK;
@@ -994,6 +1053,8 @@ void pfhip_destroy(pfhip_model* m) {
   if (!m) return;
   for (pfhip_model* r : m->replicas) pfhip_destroy(r);
   m->replicas.clear();
+  for (pfhip_model* cx : m->contexts) pfhip_destroy(cx);
+  m->contexts.clear();
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
@@ -1001,12 +1062,11 @@ void pfhip_destroy(pfhip_model* m) {
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
                  &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst})
     b->release();
-  for (void* p : {(void*)m->d_blob, (void*)m->d_w0qkv, (void*)m->d_predconv, (void*)m->d_vocab_bias, (void*)m->d_window, (void*)m->d_tw,
-                  (void*)m->d_mel_off, (void*)m->d_mel_size, (void*)m->d_mel_w, (void*)m->d_inv_ts, (void*)m->d_up_w, (void*)m->d_up_b,
-                  (void*)m->d_wih, (void*)m->d_bih, (void*)m->d_whh, (void*)m->d_kv_all_w, (void*)m->d_kv_all_b, (void*)m->d_lnw_qkv, (void*)m->d_lnb_qkv,
-                  (void*)m->d_lnw_ffn1, (void*)m->d_lnb_ffn1, (void*)m->d_lns_qkv, (void*)m->d_lns_ffn1, (void*)m->d_dlnw1, (void*)m->d_dlnb1, (void*)m->d_dlns1,
-                  (void*)m->d_dlnw2, (void*)m->d_dlnb2, (void*)m->d_dlns2, (void*)m->d_dlnw3, (void*)m->d_dlnb3, (void*)m->d_dlns3})
-    if (p) (void)hipFree(p);
+  if (!m->weights_of) {          // a context borrows these
+#define X(f) if (m->f) (void)hipFree((void*)m->f);
+    PFHIP_WEIGHT_PTRS(X)
+#undef X
+  }
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_ops) (void)hipHostFree(m->h_ops);
   if (m->h_counts) (void)hipHostFree(m->h_counts);
@@ -1065,34 +1125,80 @@ static pfhip_status forward_direct(pfhip_model* m, const float* const* pcm, cons
   return fetch_locked(m, out, s);
 }
 
+// ---- execution slots -----------------------------------------------------------------------------------------------
+// A handle fronts one or more execution slots: the contexts of its device (pfhip_set_inflight) and of every replica device
+// (pfhip_create_group).  `slots` on the head lists them device-major per round (context 0 of every device, then context 1 of
+// every device, ...), so that filling them in order spreads calls over the GPUs before it stacks them on one.
+static void rebuild_slots_locked(pfhip_model* head) {
+  head->slots.clear();
+  std::vector<pfhip_model*> devs{head};
+  for (pfhip_model* r : head->replicas) devs.push_back(r);
+  size_t rounds = 0;
+  for (pfhip_model* d : devs) rounds = std::max(rounds, d->contexts.size() + 1);
+  for (size_t k = 0; k < rounds; ++k)
+    for (pfhip_model* d : devs) {
+      if ((int)k >= head->ctx_limit) continue;
+      if (k == 0) head->slots.push_back(d);
+      else if (k - 1 < d->contexts.size()) head->slots.push_back(d->contexts[k - 1]);
+    }
+}
+
+// least-loaded slot (ties: round-robin); used by calls that bypass the queue
+static pfhip_model* acquire_slot(pfhip_model* head) {
+  std::lock_guard<std::mutex> l(head->bq.mu);
+  if (head->slots.empty()) rebuild_slots_locked(head);
+  const size_t n = head->slots.size();
+  const unsigned start = head->rr.fetch_add(1);
+  pfhip_model* best = nullptr;
+  int best_load = 0;
+  for (size_t k = 0; k < n; ++k) {
+    pfhip_model* r = head->slots[(start + k) % n];
+    const int load = r->inflight.load();
+    if (!best || load < best_load) { best = r; best_load = load; }
+  }
+  ++best->inflight;
+  return best;
+}
+static void release_slot(pfhip_model* head, pfhip_model* slot) {
+  --slot->inflight;
+  head->bq.slot_freed();
+}
+
 // ---- cross-request batching ---------------------------------------------------------------------------------
 // The reference server runs `decoder-thread-num` threads that each call Forward on the shared handle with their own
 // request (websocket/bin/funasr-wss-server.cpp:479-481); its dynamic batcher only groups segments of ONE request
 // (audio.cpp:1056-1084).  On one MI355X a single 60-s segment fills 1/16 of the GEMM grid, so concurrent callers are
-// merged here: the first caller to arrive leads, waits up to `wait_us` for others, runs ONE packed forward for all
-// queued utterances and hands every caller its own slice.  Results are identical to separate calls (packed layout,
-// per-utterance masks: tests/test_gpu_forward.py::test_batch_composition_invariance).
+// merged here: callers queue at the handle, the one at the front leads — claims an idle execution slot, gathers company
+// (PoolQueue: no wait at all when nothing else is in flight), runs ONE packed forward for the utterances it took and hands
+// every caller its own slice — while the next caller in line already gathers the next batch for the next idle slot.
+// Results are identical to separate calls (packed layout, per-utterance masks:
+// tests/test_gpu_forward.py::test_batch_composition_invariance).
 struct BatchReq : pfhip_detail::MergeReqBase {
   const float* const* pcm; const int* n; int batch; pfhip_out* out;
   pfhip_status st = PFHIP_OK; std::string err;
 };
 
-// one packed forward for everybody in `take`
+// one packed forward on `m` for everybody in `take`
 static void run_batch_requests(pfhip_model* m, const std::vector<BatchReq*>& take) {
   std::vector<const float*> ptrs; std::vector<int> lens;
-  bool want_logp = false; int max_tok = 1, utts = 0;
+  bool want_logp = false, want_us = false; int max_tok = 1, utts = 0;
   for (BatchReq* r : take) {
     for (int i = 0; i < r->batch; ++i) { ptrs.push_back(r->pcm[i]); lens.push_back(r->n[i]); max_tok = std::max(max_tok, r->n[i] / 960 + 2); }
     want_logp = want_logp || r->out->logp != nullptr;
+    want_us = want_us || r->out->us_alphas || r->out->us_peaks || r->out->us_len;
     utts += r->batch;
   }
-  const int V = m->cfg.vocab;
-  std::vector<int32_t> ids((size_t)utts * max_tok), tn(utts), nf(utts), fr(utts);
-  std::vector<float> logp;
+  const int V = m->cfg.vocab, max_us = 3 * max_tok;
+  std::vector<int32_t> ids((size_t)utts * max_tok), tn(utts), nf(utts), fr(utts), usl;
+  std::vector<float> logp, usa, usp;
   if (want_logp) logp.resize((size_t)utts * max_tok * V);
   pfhip_out all{};
   all.token_ids = ids.data(); all.token_num = tn.data(); all.n_fires = nf.data(); all.n_frames = fr.data();
   all.logp = want_logp ? logp.data() : nullptr; all.max_tokens = max_tok;
+  if (want_us) {
+    usa.resize((size_t)utts * max_us); usp.resize((size_t)utts * max_us); usl.resize(utts);
+    all.us_alphas = usa.data(); all.us_peaks = usp.data(); all.us_len = usl.data(); all.max_us = max_us;
+  }
   pfhip_status st = forward_direct(m, ptrs.data(), lens.data(), utts, nullptr, 0, &all);
   const std::string err = g_err;
   int u0 = 0;
@@ -1100,28 +1206,46 @@ static void run_batch_requests(pfhip_model* m, const std::vector<BatchReq*>& tak
     r->st = st; r->err = err;
     for (int i = 0; i < r->batch && st == PFHIP_OK; ++i) {
       const int u = u0 + i;
-      if (r->out->token_num) r->out->token_num[i] = tn[u];
-      if (r->out->n_fires) r->out->n_fires[i] = nf[u];
-      if (r->out->n_frames) r->out->n_frames[i] = fr[u];
-      if ((r->out->token_ids || r->out->logp) && r->out->max_tokens < nf[u]) {
+      pfhip_out* o = r->out;
+      if (o->token_num) o->token_num[i] = tn[u];
+      if (o->n_fires) o->n_fires[i] = nf[u];
+      if (o->n_frames) o->n_frames[i] = fr[u];
+      if ((o->token_ids || o->logp) && o->max_tokens < nf[u]) {
         r->st = PFHIP_ERR_CAPACITY; r->err = "max_tokens smaller than the longest token sequence"; break;
       }
-      if (r->out->token_ids) std::memcpy(r->out->token_ids + (size_t)i * r->out->max_tokens, ids.data() + (size_t)u * max_tok, 4 * (size_t)nf[u]);
-      if (r->out->logp) std::memcpy(r->out->logp + (size_t)i * r->out->max_tokens * V, logp.data() + (size_t)u * max_tok * V, 4 * (size_t)nf[u] * V);
+      if (o->token_ids) std::memcpy(o->token_ids + (size_t)i * o->max_tokens, ids.data() + (size_t)u * max_tok, 4 * (size_t)nf[u]);
+      if (o->logp) std::memcpy(o->logp + (size_t)i * o->max_tokens * V, logp.data() + (size_t)u * max_tok * V, 4 * (size_t)nf[u] * V);
+      if (o->us_alphas || o->us_peaks || o->us_len) {
+        if (o->us_len) o->us_len[i] = usl[u];
+        if ((o->us_alphas || o->us_peaks) && o->max_us < usl[u]) { r->st = PFHIP_ERR_CAPACITY; r->err = "max_us smaller than 3 x frames"; break; }
+        if (o->us_alphas) std::memcpy(o->us_alphas + (size_t)i * o->max_us, usa.data() + (size_t)u * max_us, 4 * (size_t)usl[u]);
+        if (o->us_peaks) std::memcpy(o->us_peaks + (size_t)i * o->max_us, usp.data() + (size_t)u * max_us, 4 * (size_t)usl[u]);
+      }
     }
     u0 += r->batch;
   }
 }
 
-static pfhip_status forward_batched(pfhip_model* m, const float* const* pcm, const int* n_samples, int batch,
+namespace { thread_local pfhip_model* tl_last_replica = nullptr; }      // where this thread's last offline forward ran (debug getters)
+
+static pfhip_status forward_batched(pfhip_model* head, const float* const* pcm, const int* n_samples, int batch,
                                     pfhip_out* out) {
   BatchReq me;
   me.pcm = pcm; me.n = n_samples; me.batch = batch; me.out = out;
   int wait_us, max_utts;
-  { std::lock_guard<std::mutex> l(m->bq.mu); wait_us = m->batch_wait_us; max_utts = m->batch_max_utts; }
-  m->bq.submit(
+  { std::lock_guard<std::mutex> l(head->bq.mu); wait_us = head->batch_wait_us; max_utts = head->batch_max_utts; }
+  pfhip_model* ran_on = nullptr;
+  head->bq.submit(
       me, wait_us,
-      // gather: wait for co-arriving requests, bounded by time and by utterance count
+      // claim (under the queue lock): an idle slot, in the device-major order of `slots`
+      [&]() -> pfhip_model* {
+        if (head->slots.empty()) rebuild_slots_locked(head);
+        for (pfhip_model* r : head->slots)
+          if (r->inflight.load() == 0) { ++r->inflight; return r; }
+        return nullptr;
+      },
+      [&](pfhip_model* r) { --r->inflight; },
+      // gather: bounded by time and by utterance count
       [&](const std::deque<BatchReq*>& q) { int u = 0; for (BatchReq* r : q) u += r->batch; return u >= max_utts; },
       [&](std::deque<BatchReq*>& q, std::vector<BatchReq*>& take) {
         int utts = 0;
@@ -1131,12 +1255,17 @@ static pfhip_status forward_batched(pfhip_model* m, const float* const* pcm, con
           q.pop_front();
         }
       },
-      [&](std::vector<BatchReq*>& take) { run_batch_requests(m, take); });
+      [&](pfhip_model* r, std::vector<BatchReq*>& take) {
+        ran_on = r;
+        int utts = 0;
+        for (BatchReq* q : take) utts += q->batch;
+        run_batch_requests(r, take);
+        ++r->served_forwards; r->served_calls += (int64_t)take.size(); r->served_utts += utts;
+      });
+  if (ran_on) tl_last_replica = ran_on;       // the leader's own slice ran there; followers ask the handle (pfhip_get_tensor: head)
   if (me.st != PFHIP_OK) g_err = me.err;
   return me.st;
 }
-
-namespace { thread_local pfhip_model* tl_last_replica = nullptr; }      // where this thread's last offline forward ran (debug getters)
 
 pfhip_status pfhip_offline_forward(pfhip_model* head, const float* const* pcm, const int* n_samples, int batch,
                                    const float* hw_emb, int n_hotwords, pfhip_out* out) {
@@ -1144,26 +1273,106 @@ pfhip_status pfhip_offline_forward(pfhip_model* head, const float* const* pcm, c
   if (!head || !pcm || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
   for (int i = 0; i < batch; ++i)
     if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
-  pfhip_model* m = route_offline(head);                  // the replica (= GPU) with the fewest calls in flight
-  struct InFlight {
-    pfhip_model* r; int n;
-    InFlight(pfhip_model* r_, int n_) : r(r_), n(n_) { ++r->inflight; }
-    ~InFlight() { --r->inflight; ++r->served_calls; r->served_utts += n; }
-  } guard(m, batch);
+  // merged with whoever else is calling (plain and timestamp models; hotwords are per connection, so contextual calls are not)
+  if (head->batch_wait_us > 0 && !head->cfg.contextual && batch < head->batch_max_utts)
+    return forward_batched(head, pcm, n_samples, batch, out);
+  pfhip_model* m = acquire_slot(head);                  // the least-loaded execution slot (context / GPU)
   tl_last_replica = m;
-  if (m->batch_wait_us > 0 && !m->cfg.contextual && !m->cfg.timestamp && batch < m->batch_max_utts)
-    return forward_batched(m, pcm, n_samples, batch, out);
-  return forward_direct(m, pcm, n_samples, batch, hw_emb, n_hotwords, out);
+  const pfhip_status st = forward_direct(m, pcm, n_samples, batch, hw_emb, n_hotwords, out);
+  ++m->served_forwards; ++m->served_calls; m->served_utts += batch;
+  release_slot(head, m);
+  return st;
+}
+
+// pfhip_offline_forward with the PCM already in HBM: same routing over the execution slots, no H2D of the audio
+pfhip_status pfhip_offline_forward_resident(pfhip_model* head, const float* d_pcm, const int64_t* sample_off, const int* n_samples,
+                                            int batch, pfhip_out* out) {
+  g_err.clear();
+  if (!head || !d_pcm || !sample_off || !n_samples || batch <= 0 || !out) return fail(PFHIP_ERR_ARG, "bad argument");
+  if (head->cfg.contextual && head->n_hw <= 0) return fail(PFHIP_ERR_ARG, "hw_emb is null");
+  pfhip_model* m = acquire_slot(head);
+  tl_last_replica = m;
+  pfhip_status st;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipStream_t s = m->own_stream;
+    m->prof_stream = s;
+    st = enqueue_locked(m, d_pcm, sample_off, n_samples, batch, s, false);
+    if (!st) st = head_locked(m, s, out->logp != nullptr);
+    if (!st) st = fetch_locked(m, out, s);
+  }
+  ++m->served_forwards; ++m->served_calls; m->served_utts += batch;
+  release_slot(head, m);
+  return st;
 }
 
 pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances) {
   g_err.clear();
   if (!m || wait_us < 0 || max_utterances < 1) return fail(PFHIP_ERR_ARG, "bad argument");
-  for (size_t i = 0; i <= m->replicas.size(); ++i) {
-    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
-    std::lock_guard<std::mutex> ql(r->bq.mu);
-    r->batch_wait_us = wait_us;
-    r->batch_max_utts = max_utterances;
+  std::lock_guard<std::mutex> ql(m->bq.mu);
+  m->batch_wait_us = wait_us;
+  m->batch_max_utts = max_utterances;
+  return PFHIP_OK;
+}
+
+// every execution slot of the handle, for calls that configure all of them
+static std::vector<pfhip_model*> all_slots(pfhip_model* head) {
+  std::lock_guard<std::mutex> l(head->bq.mu);
+  if (head->slots.empty()) rebuild_slots_locked(head);
+  return head->slots;
+}
+
+pfhip_status pfhip_set_inflight(pfhip_model* head, int n) {
+  g_err.clear();
+  if (!head || n < 1 || n > 16) return fail(PFHIP_ERR_ARG, "in-flight count outside 1..16");
+  if (head->group_head || head->weights_of) return fail(PFHIP_ERR_ARG, "not the handle pfhip_create returned");
+  std::vector<pfhip_model*> devs{head};
+  for (pfhip_model* r : head->replicas) devs.push_back(r);
+  std::vector<float> hw;
+  { std::lock_guard<std::mutex> l(head->bq.mu); hw = head->hw_host; }
+  for (pfhip_model* d : devs) {
+    while ((int)d->contexts.size() + 1 < n) {
+      pfhip_model* cx = nullptr;
+      pfhip_status st = build_context(d, &cx);
+      if (st) return st;
+      cx->group_head = head;
+      cx->ctx_index = (int)d->contexts.size() + 1;
+      if (!hw.empty()) {
+        std::lock_guard<std::mutex> lk(cx->mu);
+        st = set_hotwords_locked(cx, hw.data(), (int)(hw.size() / (size_t)head->cfg.d_model), cx->own_stream);
+        if (st) { pfhip_destroy(cx); return st; }
+      }
+      std::lock_guard<std::mutex> l(head->bq.mu);
+      d->contexts.push_back(cx);
+    }
+  }
+  // fewer than before: the extra contexts stay allocated (a call may be running on one) but leave the slot list
+  std::lock_guard<std::mutex> l(head->bq.mu);
+  head->ctx_limit = n;
+  rebuild_slots_locked(head);
+  return PFHIP_OK;
+}
+
+int pfhip_get_inflight(const pfhip_model* m) {
+  if (!m) return 0;
+  pfhip_model* head = const_cast<pfhip_model*>(m);
+  std::lock_guard<std::mutex> l(head->bq.mu);
+  if (head->slots.empty()) rebuild_slots_locked(head);
+  int n = 0;
+  for (pfhip_model* sl : head->slots) n = std::max(n, sl->ctx_index + 1);
+  return n;
+}
+
+pfhip_status pfhip_inflight_stats(pfhip_model* head, pfhip_slot_stats* out, int cap, int* n_out) {
+  g_err.clear();
+  if (!head || !n_out) return fail(PFHIP_ERR_ARG, "bad argument");
+  const std::vector<pfhip_model*> sl = all_slots(head);
+  *n_out = (int)sl.size();
+  if (!out || cap < (int)sl.size()) return fail(PFHIP_ERR_CAPACITY, "slot array too small");
+  for (size_t i = 0; i < sl.size(); ++i) {
+    out[i].device = sl[i]->device; out[i].context = sl[i]->ctx_index;
+    out[i].forwards = sl[i]->served_forwards.load(); out[i].calls = sl[i]->served_calls.load();
+    out[i].utterances = sl[i]->served_utts.load();
   }
   return PFHIP_OK;
 }
@@ -1171,13 +1380,14 @@ pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances)
 pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwords) {
   g_err.clear();
   if (!m || !hw_emb || n_hotwords <= 0) return fail(PFHIP_ERR_ARG, "bad argument");
-  for (size_t i = 0; i <= m->replicas.size(); ++i) {
-    pfhip_model* r = i == 0 ? m : m->replicas[i - 1];
+  for (pfhip_model* r : all_slots(m)) {
     std::lock_guard<std::mutex> lk(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     pfhip_status st = set_hotwords_locked(r, hw_emb, n_hotwords, r->own_stream);
     if (st) return st;
   }
+  std::lock_guard<std::mutex> l(m->bq.mu);
+  m->hw_host.assign(hw_emb, hw_emb + (size_t)n_hotwords * m->cfg.d_model);
   return PFHIP_OK;
 }
 

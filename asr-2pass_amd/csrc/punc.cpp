@@ -241,7 +241,8 @@ static pfhip_status punc_infer_queued(pfhip_punc* p, const int32_t* ids, int n, 
                                                   out_v.data(), nullptr);
         const std::string err = last_error();
         for (PuncReq* r : take) { r->st = st; r->err = err; }
-      });
+      },
+      /*fresh_no_wait=*/true);          // a lone caller runs at once; company gathers behind the pass that is executing
   if (me.st != PFHIP_OK) last_error() = me.err;
   return me.st;
 }

@@ -203,6 +203,29 @@ def synth_vad_weights(cfg=None, seed=4321):
     return synth_generic(cfg, vad_tensor_specs(cfg), seed)
 
 
+def energy_vad_weights(man, blob):
+    """Random VAD weights do not tell speech from silence.  For flows that need real segments (bench.py's long-audio block, the
+    pipeline tests) shape them so that class 0 follows the frame energy: every weight zeroed except one path — mean log-mel of the
+    centre frame -> unit 0 of every layer -> a negative slope on the silence logit.  Returns (manifest, blob), edited in place."""
+    def view(name):
+        meta = man["tensors"][name]
+        n = int(np.prod(meta["shape"]))
+        o = meta["offset"] // 4
+        return blob[o:o + n].reshape(meta["shape"])
+    for k in man["tensors"]:
+        if (k.endswith(".w") or k.endswith(".b")) and not k.startswith("cmvn"):
+            view(k)[...] = 0
+    view("in1.w")[0, 160:240] = 1.0 / 80
+    view("in2.w")[0, 0] = 1.0
+    for i in range(man["config"]["layers"]):
+        view(f"blk.{i}.linear.w")[0, 0] = 1.0
+        view(f"blk.{i}.affine.w")[0, 0] = 1.0
+    view("out1.w")[0, 0] = 1.0
+    view("out2.w")[0, 0] = -4.0
+    view("out2.b")[0] = 8.0          # energy ~ (x - 8) * 0.3 after CMVN: silence (log eps) strongly negative -> relu 0
+    return man, blob
+
+
 # ---- CT-Transformer punctuation (SURVEY §8a row a15; UPSTREAM: vocab 272727, 256-d SAN-M x4, 8 heads, FFN 1024) ----
 CT_TRANSFORMER = dict(model="ct_transformer", vocab=272727, d_model=256, n_head=8, ffn=1024, layers=4, kernel=11, n_punc=6)
 

@@ -105,6 +105,113 @@ def streaming_block(pkg, model, weight_bytes, rng):
     return out
 
 
+def c4_block(pkg, weights, utts, seconds, n_fly):
+    """BASELINE.json configs[3] (C4): the contextual (hotword) + timestamp Paraformer-large — bias decoder in the last layer, 16
+    hotwords compiled on the device, CifPredictorV3 upsampling head with its BLSTM — batch = 32 x 30 s, host buffers in, ids +
+    upsampled alphas / peaks out (what TimestampOnnx consumes)."""
+    cfg = dict(weights.PARAFORMER_LARGE, contextual=1, timestamp=1)
+    man, blob = weights.synth_weights(cfg, seed=1234)
+    h = pkg.ParaformerHip().InitAsr((man, blob))
+    rng = np.random.default_rng(SEED_PCM + 4)
+    hot = [list(rng.integers(2, 8000, int(rng.integers(2, 7)))) for _ in range(16)]           # SURVEY §8d: H = 16, lengths 2-6
+    hw = h.CompileHotwordEmbedding(hot)
+    h.forward_ids(utts, hw_emb=hw, want_timestamps=True)
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = h.forward_ids(utts, hw_emb=hw, want_timestamps=True)
+    dt = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        h.forward_ids(utts, hw_emb=hw)
+    dt_no_ts = (time.perf_counter() - t0) / n
+    out = {"workload": f"contextual + timestamp Paraformer-large, batch={len(utts)} x {seconds} s, H=16 hotwords (BASELINE.json configs[3])",
+           "ms_per_batch": 1e3 * dt, "audio_s_per_s": len(utts) * seconds / dt, "ms_per_batch_without_timestamp_head": 1e3 * dt_no_ts,
+           "tokens": int(sum(len(x) for x in r["ids"])), "us_len": int(len(r["us_alphas"][0])),
+           "boundary": "host float** buffers in; ids, us_alphas, us_cif_peak out"}
+    if n_fly > 1:                   # the same batches from n_fly threads on the one handle (contexts share the weights)
+        h.set_inflight(n_fly)
+        k = 2
+
+        def calls(_):
+            for _ in range(k):
+                h.forward_ids(utts, hw_emb=hw, want_timestamps=True)
+        calls(0)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=calls, args=(i,)) for i in range(n_fly)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dtf = (time.perf_counter() - t0) / (k * n_fly)
+        out["ms_per_batch_in_flight"] = 1e3 * dtf
+        out["audio_s_per_s_in_flight"] = len(utts) * seconds / dtf
+        out["in_flight"] = n_fly
+    h.close()
+    return out
+
+
+def c5_block(pkg, weights, model, n_files=8, seconds=600, workers=8):
+    """BASELINE.json configs[4] (C5) on ONE GPU: long files (8 x 600 s, seeded 1-s silences every 7-25 s) -> FSMN-VAD over the whole
+    file in one pass -> end-point detector (host) -> length-sorted FetchDynamic batches -> the offline model, from 8 concurrent
+    decoder workers that share ONE handle (merged by pfhip_set_batching into packed launches over the handle's contexts).
+    `model` is the headline Paraformer-large handle (contexts already set)."""
+    import importlib
+    pipeline = importlib.import_module("asr_2pass_amd.pipeline")
+    rng = np.random.default_rng(SEED_PCM + 5)
+
+    def make_file(i):
+        parts, t = [], 0.0
+        while t < seconds:
+            dur = min(float(rng.uniform(7, 25)), seconds - t)
+            parts.append(synth_pcm(i, int(dur * SR), rng))
+            parts.append(np.zeros(SR, np.float32))          # 1.0-s gaps: longer than the 800-ms end-silence threshold
+            t += dur + 1.0
+        return np.concatenate(parts)[:seconds * SR]
+    files = [make_file(i) for i in range(n_files)]
+    vman, vblob = weights.synth_vad_weights()
+    vman, vblob = weights.energy_vad_weights(vman, vblob)
+    vad = pkg.FsmnVadHip().InitVad((vman, vblob))
+    segs_of = [None] * n_files
+    ntok = [0] * n_files
+    model.set_batching(3000, 96)
+    nxt = [0]
+    lock = threading.Lock()
+
+    def worker():
+        seg = pkg.E2EVadModelHost()
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= n_files:
+                break
+            ids, frames = pipeline.infer_buffer(files[i], model, vad, seg, batch_size=32)
+            segs_of[i] = len(frames)
+            ntok[i] = sum(len(x) for x in ids)
+        seg.close()
+    seg0 = pkg.E2EVadModelHost()
+    pipeline.infer_buffer(files[0][:SR * 120], model, vad, seg0, batch_size=32)      # warm-up
+    seg0.close()
+    before = model.inflight_stats()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker) for _ in range(workers)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    after = model.inflight_stats()
+    model.set_batching(0, 32)
+    vad.close()
+    fw = sum(a["forwards"] - b["forwards"] for a, b in zip(after, before))
+    ut = sum(a["utterances"] - b["utterances"] for a, b in zip(after, before))
+    return {"workload": f"{n_files} x {seconds}-s files, FSMN-VAD segmented, {workers} concurrent decoder workers on one handle, 1 GPU "
+                        f"(BASELINE.json configs[4]; the 8-GPU form shards files over replicas)",
+            "xRT": n_files * seconds / dt, "wall_s": dt, "segments": int(sum(segs_of)), "tokens": int(sum(ntok)),
+            "packed_forwards": int(fw), "utterances_per_forward": ut / max(1, fw), "in_flight": model.get_inflight()}
+
+
 def cpu_baseline(man, blob, utts, seconds_per_utt):
     """The oracle (CPU restatement, numpy/OpenBLAS fp32) timed in the reference's threading shape:
     W worker threads sharing one model, 1 BLAS thread each, batch 1 per call
@@ -145,9 +252,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-streaming", action="store_true", help="skip the C3 streaming block (rank 0, N = 1 only)")
+    ap.add_argument("--no-c4c5", action="store_true", help="skip the C4 (hotword + timestamp) and C5 (long audio) blocks (rank 0, N = 1 only)")
     ap.add_argument("--in-flight", type=int, default=3,
-                    help="batches in flight per GPU in the timed region behind `value` (model replicas on the device, one host thread and "
-                         "one stream each); 1 = back to back.  The back-to-back figures and the roofline are always measured too")
+                    help="batches in flight per GPU in the timed region behind `value` (execution contexts of the one handle, one caller "
+                         "thread each); 1 = back to back.  The back-to-back figures and the roofline are always measured too")
     args = ap.parse_args()
 
     import torch
@@ -188,31 +296,24 @@ def main():
         model.enqueue_device(d_pcm.data_ptr(), sample_off, n_samples, stream.cuda_stream)
         return model.fetch(args.batch, max_tokens)
 
-    # Several batches in flight (the reference's serving shape is concurrent decoder threads: funasr-wss-server.cpp:479-481,
-    # run_server_offline.sh:39).  One launch of this workload already fills the chip; what a second and third batch in flight buy is
-    # their matrix-core phases over another batch's bandwidth-bound ones (epilogues, FSMN prologue, the host round trip for the token
-    # counts): tools/two_batches_probe.py measured 41.0 -> 38.6 (2) -> 37.8 (3) -> 38.4 (4) ms per batch on one box.
+    # Several batches in flight (the reference's serving shape is concurrent decoder threads on ONE shared session:
+    # funasr-wss-server.cpp:479-481, paraformer.cpp:35-41,541, run_server_offline.sh:39).  One launch of this workload already fills
+    # the chip; what a second and third batch in flight buy is their matrix-core phases over another batch's bandwidth-bound ones
+    # (epilogues, FSMN prologue, launch boundaries, the host round trip for the token counts).  They run on execution contexts of
+    # the ONE handle (pfhip_set_inflight: one weight set, n workspaces), n_fly caller threads, PCM resident in HBM.
     n_fly = max(1, args.in_flight)
-    replicas = [model]
-    try:
-        for _ in range(n_fly - 1):
-            replicas.append(pkg.ParaformerHip().InitAsr((man, blob), device=local_rank))
-    except Exception as e:              # a replica that cannot be built (memory on a shared node) must not cost the run its numbers
-        print(f"bench.py: {len(replicas)} batch(es) in flight instead of {n_fly}: {e}", file=sys.stderr)
-    n_fly = len(replicas)
-    rstreams = [stream] + [torch.cuda.Stream(device=local_rank) for _ in range(n_fly - 1)]
+    last_of_thread = [None] * n_fly
 
-    last_of_replica = [None] * n_fly
-
-    def run_replica(i, k):
+    def run_thread(i, k, host):
         for _ in range(k):
-            replicas[i].enqueue_device(d_pcm.data_ptr(), sample_off, n_samples, rstreams[i].cuda_stream)
-            last_of_replica[i] = replicas[i].fetch(args.batch, max_tokens)
+            if host:
+                last_of_thread[i] = model.forward_ids(utts, max_tokens=max_tokens)
+            else:
+                last_of_thread[i] = model.forward_resident(d_pcm.data_ptr(), sample_off, n_samples, max_tokens)
 
-    def steps_in_flight(k):
-        import threading
+    def steps_in_flight(k, host=False):
         share = [k // n_fly + (1 if i < k % n_fly else 0) for i in range(n_fly)]
-        th = [threading.Thread(target=run_replica, args=(i, share[i])) for i in range(n_fly) if share[i]]
+        th = [threading.Thread(target=run_thread, args=(i, share[i], host)) for i in range(n_fly) if share[i]]
         for t in th:
             t.start()
         for t in th:
@@ -220,8 +321,6 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
-    if n_fly > 1:
-        steps_in_flight(max(args.warmup, n_fly))
     # HIP events around the launches of the dominant kernel class only (the fp32 GEMM): bracketing all ~1000
     # launches of a step costs ~6 % of the step, bracketing the 284 GEMMs ~1 %
     model.profile_enable(0 if args.no_profile else GEMM_ONLY_MASK)
@@ -249,27 +348,44 @@ def main():
         model.profile_enable(0)
     dt = max_over_ranks(dt, dist, torch.device("cuda", local_rank))
     dt_seq = dt
-    # (the branch is taken by every rank or by none — args.in_flight, not the replica count a rank ended up with — so the
-    # barriers inside it cannot leave a rank behind)
-    if args.in_flight > 1:       # the same K steps, n_fly of them in flight: this timed region is the one behind `value`
-        if dist is not None:
-            dist.barrier()
+    # the same K steps, n_fly of them in flight on the one handle: this timed region is the one behind `value`
+    # (every rank runs the same sequence of collectives: nothing below raises between two barriers)
+    try:
+        if n_fly > 1:
+            model.set_inflight(n_fly)
+    except Exception as e:          # contexts that cannot be built (memory on a shared node) must not cost the run its numbers
+        print(f"bench.py: 1 batch in flight instead of {n_fly}: {e}", file=sys.stderr)
+    n_fly = model.get_inflight()
+    steps_in_flight(max(args.warmup, n_fly))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps_in_flight(args.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        steps_in_flight(args.steps)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        dt = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
-        for got in last_of_replica:        # every replica, under concurrency, returns what the back-to-back run returned
-            assert got is None or all(list(a) == list(b) for a, b in zip(got["ids"], res["ids"]))
-        for r_ in replicas[1:]:
-            r_.close()
+    dt = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+    for got in last_of_thread:        # every context, under concurrency, returns what the back-to-back run returned
+        assert got is None or all(list(a) == list(b) for a, b in zip(got["ids"], res["ids"]))
+    slots = model.inflight_stats()
     # the same K steps on the reference's own boundary: host float** buffers in (Model::Forward(float** din, ...), H2D inside
-    # the timed region where paraformer-torch.cpp:355-358 has it), ids out — reported beside `value`, never as `value`
-    for _ in range(min(args.warmup, 2)):
-        model.forward_ids(utts, max_tokens=max_tokens)
+    # the timed region where paraformer-torch.cpp:355-358 has it), ids out — reported beside `value`, never as `value`:
+    # in flight on the one handle (n_fly caller threads, as the server's decoder threads), then back to back from one thread
+    steps_in_flight(min(max(args.warmup, 1), 2) * n_fly, host=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps_in_flight(args.steps, host=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt_host_fly = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
+    for got in last_of_thread:
+        assert got is None or all(list(a) == list(b) for a, b in zip(got["ids"], res["ids"]))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -282,34 +398,6 @@ def main():
         torch.cuda.synchronize()
     dt_host = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
     assert all(list(a) == list(b) for a, b in zip(res_h["ids"], res["ids"]))
-    # ... and through the product's router: ONE handle fronting n_fly replicas on this device (pfhip_create_group — what
-    # PFHIP_DEVICES=d,d,d gives the unchanged server), n_fly caller threads as the server's decoder threads
-    dt_host_grp = None
-    if args.in_flight > 1:
-        local_dt = -1.0             # no collective inside the try: a rank that fails here must not strand the others
-        try:
-            grp = pkg.ParaformerHip().InitAsr((man, blob), devices=[local_rank] * n_fly)
-            share = [args.steps // n_fly + (1 if i < args.steps % n_fly else 0) for i in range(n_fly)]
-
-            def host_calls(k):
-                for _ in range(k):
-                    grp.forward_ids(utts, max_tokens=max_tokens)
-            host_calls(n_fly)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            th = [threading.Thread(target=host_calls, args=(k,)) for k in share if k]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            torch.cuda.synchronize()
-            local_dt = time.perf_counter() - t0
-            grp.close()
-        except Exception as e:
-            print(f"bench.py: router leg skipped: {e}", file=sys.stderr)
-        failed = max_over_ranks(1.0 if local_dt < 0 else 0.0, dist, torch.device("cuda", local_rank))
-        slowest = max_over_ranks(max(local_dt, 0.0), dist, torch.device("cuda", local_rank))
-        dt_host_grp = None if failed > 0 else slowest
 
     audio_per_step = world * args.batch * args.seconds
     value = audio_per_step * args.steps / dt
@@ -322,18 +410,23 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (operands split exactly into 3 bf16 planes, products on the BF16 matrix cores, fp32 accumulate)",
             "data": "synthetic",
+            "value_host_buffers_in_flight": audio_per_step * args.steps / dt_host_fly,
+            "ms_per_step_host_buffers_in_flight": 1e3 * dt_host_fly / args.steps,
             "value_host_buffers": audio_per_step * args.steps / dt_host, "ms_per_step_host_buffers": 1e3 * dt_host / args.steps,
-            "value_host_buffers_router": (audio_per_step * args.steps / dt_host_grp) if dt_host_grp else None,
+            "value_host_buffers_router": audio_per_step * args.steps / dt_host_fly,
             "host_buffers_note": "same steps through pfhip_offline_forward(float** host pcm): the 61 MB H2D copy of the batch is "
-                                 "inside the timed region (the reference's Model::Forward boundary); `value` has the PCM resident in HBM; "
-                                 "`value_host_buffers_router`: the same calls from in_flight threads on ONE handle that fronts in_flight "
-                                 "replicas on the device (pfhip_create_group / PFHIP_DEVICES=d,d,d: the unchanged server's decoder threads)",
+                                 "inside the timed region (the reference's Model::Forward boundary); `value` has the PCM resident in HBM. "
+                                 "`value_host_buffers_in_flight`: in_flight caller threads on the ONE handle (the unchanged server's decoder "
+                                 "threads on one shared model); `value_host_buffers`: one thread, back to back; "
+                                 "`value_host_buffers_router`: round-2 key, now the same number as `value_host_buffers_in_flight`",
             "value_one_in_flight": audio_per_step * args.steps / dt_seq, "ms_per_step_one_in_flight": 1e3 * dt_seq / args.steps,
-            "in_flight_note": f"`value` / `ms_per_step`: the K steps with {n_fly} batches in flight per GPU ({n_fly} model replicas on the "
-                              "device, one host thread and stream each — the reference serves with concurrent decoder threads); "
-                              "`*_one_in_flight`: the same K steps back to back on one replica, which is also the timed region the "
-                              "roofline's HIP events bracket (with several batches in flight a launch's event-to-event time is not "
-                              "its own) and the command behind profiles/ (`--in-flight 1`)",
+            "in_flight_note": f"`value` / `ms_per_step`: the K steps from {n_fly} caller threads on ONE handle whose {n_fly} execution "
+                              "contexts (workspace + stream each) share one weight set (pfhip_set_inflight) — the reference serves with "
+                              "concurrent decoder threads on one shared session; `*_one_in_flight`: the same K steps back to back on "
+                              "context 0 — the round-over-round comparable figure, the timed region the roofline's HIP events bracket "
+                              "(with several batches in flight a launch's event-to-event time is not its own) and the command behind "
+                              "profiles/ (`--in-flight 1`)",
+            "slots": slots,
             "config": {"workload": f"Paraformer-large offline, batch={args.batch} x {args.seconds} s synthetic 16 kHz "
                                    f"utterances per GPU (BASELINE.json configs[1])",
                        "in_flight": n_fly,
@@ -364,6 +457,15 @@ def main():
             }
         if world == 1 and not args.no_streaming:
             out["streaming"] = streaming_block(pkg, model, int(blob.nbytes), np.random.default_rng(SEED_PCM + 7))
+        if world == 1 and not args.no_c4c5:
+            try:
+                out["c5"] = c5_block(pkg, weights, model)
+            except Exception as e:
+                out["c5"] = {"error": str(e)}
+            try:
+                out["c4"] = c4_block(pkg, weights, utts, args.seconds, n_fly)
+            except Exception as e:
+                out["c4"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             workers = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(man, blob, utts[:workers], args.seconds)

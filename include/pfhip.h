@@ -8,8 +8,10 @@
  *
  * Threading: like the reference's `Model::Forward`, which all decoder threads call concurrently on
  * one shared handle (websocket/bin/funasr-wss-server.cpp:479-481), every entry point taking a
- * pfhip_model* is re-entrant; calls are serialised on an internal per-model lock (one GPU, one
- * workspace).
+ * pfhip_model* is re-entrant.  A handle owns ONE weight set per device and one or more execution
+ * contexts over it (workspace + streams; pfhip_set_inflight): concurrent pfhip_offline_forward calls
+ * run on different contexts — merged into packed launches first when pfhip_set_batching is on — and
+ * calls that land on the same context are serialised on its lock.
  */
 #ifndef PFHIP_H_
 #define PFHIP_H_
@@ -91,10 +93,35 @@ pfhip_status pfhip_offline_forward(pfhip_model* m, const float* const* pcm, cons
                                    int batch, const float* hw_emb, int n_hotwords, pfhip_out* out);
 
 /* Cross-request batching for the host-buffer form: with wait_us > 0, concurrent pfhip_offline_forward callers (the
- * server's decoder threads, funasr-wss-server.cpp:479-481) are merged into one packed forward of up to max_utterances
- * utterances; the first caller waits at most wait_us for others.  Results are identical to separate calls.
- * 0 switches it off (default).  Contextual models are not merged (hotwords are per connection). */
+ * server's decoder threads, funasr-wss-server.cpp:479-481) are merged into packed forwards of up to max_utterances
+ * utterances.  ONE queue per handle feeds every execution slot (contexts, replica devices): the caller at its front claims an
+ * idle slot and runs the batch it gathered while the next caller already gathers the next one.  A caller that finds nothing in
+ * flight runs at once (a lone caller never waits); while every slot is busy the gathering is free; only with an idle slot AND
+ * other batches executing does a leader wait — at most wait_us — for company.  Results are identical to separate calls.
+ * 0 switches it off (default).  Contextual models are not merged (hotwords are per connection); calls with at least
+ * max_utterances utterances go straight to the least-loaded slot. */
 pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances);
+
+/* Execution contexts: how many offline forwards of this handle may be in flight per device.  The reference shares ONE
+ * Ort::Session among all decoder threads (onnxruntime/src/paraformer.cpp:35-41,541; websocket/bin/funasr-wss-server.cpp:479-481);
+ * here the threads share one weight set (blob, repacks, LayerNorm-folded copies, front-end tables) and each forward runs on one
+ * of n contexts — a workspace, two streams and the state of its last batch, a few KB until its first forward sizes the
+ * workspace.  One launch of a large batch fills the chip, but its bandwidth-bound phases (epilogues, FSMN prologue, launch
+ * boundaries, the host round trip for the token counts) leave the matrix cores idle; a second and third batch in flight fill
+ * those gaps (+8..12 % audio-s/s at 3).  With pfhip_set_batching the merged batches are dealt to idle contexts from ONE queue.
+ * n = 1 (default) is one forward at a time.  PFHIP_INFLIGHT=n in the environment applies it to every handle created.
+ * Call at initialisation (it may allocate); contexts of a replica group are created on every device.  The device-pointer form
+ * (pfhip_offline_enqueue / _fetch), streams, pfhip_profile_* and pfhip_extract_feats use context 0. */
+pfhip_status pfhip_set_inflight(pfhip_model* m, int n);
+int pfhip_get_inflight(const pfhip_model* m);
+/* One entry per execution slot (context x device) of the handle: packed device forwards run there, caller calls and utterances
+ * they served.  utterances / forwards > calls / forwards > 1 is cross-request merging at work.  *n_out = slots (also on
+ * PFHIP_ERR_CAPACITY). */
+typedef struct {
+  int32_t device, context;
+  int64_t forwards, calls, utterances;
+} pfhip_slot_stats;
+pfhip_status pfhip_inflight_stats(pfhip_model* m, pfhip_slot_stats* out, int cap, int* n_out);
 
 /* Device-resident form (what bench.py times): d_pcm is ONE device buffer holding the utterances
  * back to back; sample_off/n_samples are host arrays.  All kernels are enqueued on `stream`
@@ -103,6 +130,12 @@ pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances)
 pfhip_status pfhip_offline_enqueue(pfhip_model* m, const float* d_pcm, const int64_t* sample_off,
                                    const int* n_samples, int batch, void* stream);
 pfhip_status pfhip_offline_fetch(pfhip_model* m, pfhip_out* out);
+/* pfhip_offline_forward for audio that is already in HBM (d_pcm / sample_off / n_samples as pfhip_offline_enqueue; the buffer
+ * must be complete and stay untouched until the call returns): the forward and the D2H of the results on the least-loaded
+ * execution slot's own stream, synchronous like the host-buffer form.  What bench.py's `value` times from several threads on
+ * ONE handle; d_pcm must live on the device of the handle (groups: device 0's slots only would see it — single-device handles). */
+pfhip_status pfhip_offline_forward_resident(pfhip_model* m, const float* d_pcm, const int64_t* sample_off, const int* n_samples,
+                                            int batch, pfhip_out* out);
 
 /* ---- hotwords (contextual model) ---------------------------------------------------------------
  *   pfhip_hotword_embed <-> the `hw_m_session->Run` on model_eb.onnx + the per-hotword row selection inside
@@ -303,10 +336,12 @@ typedef struct {
  * batch, pfhip_set_batching) to the replica with the fewest calls in flight, pfhip_stream_create pins a new connection to the
  * replica with the fewest open streams for its lifetime (device-resident caches), pfhip_set_hotwords / pfhip_set_batching /
  * pfhip_set_stream_batching apply to every replica.  Results do not depend on which replica served a call.  No data moves
- * between devices.  A device may be listed more than once (two replicas on one GPU: only useful for tests).
+ * between devices.  For several forwards in flight on ONE device use pfhip_set_inflight (contexts share the weights); listing a
+ * device twice here still works but builds a second full copy of the weights there.
  * PFHIP_DEVICES="0,1,..." in the environment makes pfhip_create / pfhip_create_from_memory build such a group (their `device`
  * argument is then ignored), so the stock server needs no code change to use every GPU of the node.
- * pfhip_offline_enqueue / pfhip_offline_fetch (device pointers) always use replica 0. */
+ * pfhip_offline_enqueue / pfhip_offline_fetch (device pointers) always use replica 0.  pfhip_group_stats counts per replica
+ * (its contexts included); pfhip_inflight_stats per execution slot. */
 pfhip_status pfhip_create_group(const void* blob, size_t blob_bytes, const char* manifest_json, const int* devices, int n_devices,
                                 pfhip_model** out);
 int pfhip_group_size(const pfhip_model* m);

@@ -1,0 +1,243 @@
+"""GPU: execution contexts over ONE weight set and the one merge queue in front of them (pfhip_set_inflight, pfhip_set_batching).
+
+The reference shares a single Ort::Session among all decoder threads (onnxruntime/src/paraformer.cpp:35-41,541;
+websocket/bin/funasr-wss-server.cpp:479-481) and initialises the model with --model-thread-num (default 1), which is NOT the
+number of those threads (funasr-wss-server.cpp:105-106,452,511).  Here: n contexts (workspace + streams) borrow the weights of
+the handle, concurrent callers are merged into packed forwards by ONE queue whose leaders take idle contexts, and none of it
+is keyed on `thread_num`."""
+import json
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no CPU fallback")
+
+
+def run_threads(fn, n):
+    err = []
+
+    def guard(i):
+        try:
+            fn(i)
+        except Exception as e:          # surfaces in the main thread
+            err.append(e)
+    ths = [threading.Thread(target=guard, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if err:
+        raise err[0]
+
+
+def test_contexts_share_one_weight_set_at_the_models_real_size(pkg, weights_mod):
+    """Device memory per extra context << the 0.88 GB of weights (hipMemGetInfo), results identical whichever context serves."""
+    need_gpu()
+    cfg = dict(weights_mod.PARAFORMER_LARGE)
+    man, blob = weights_mod.synth_weights(cfg, seed=1234)
+    rng = np.random.default_rng(3)
+    batches = [[synth_pcm(7 * k + i, 16000 * 8 + 1000 * i, rng) for i in range(4)] for k in range(3)]
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    m = pkg.ParaformerHip().InitAsr((man, blob))
+    assert m.get_inflight() == 1
+    want = [m.forward_ids(b, want_logp=True) for b in batches]            # context 0 sizes its workspace
+    free1 = torch.cuda.mem_get_info()[0]
+    weights_and_one_workspace = free0 - free1
+    assert weights_and_one_workspace >= blob.nbytes
+    m.set_inflight(3)
+    assert m.get_inflight() == 3
+    free2 = torch.cuda.mem_get_info()[0]
+    assert free1 - free2 < 8 << 20, "a context must cost next to nothing before its first forward"
+    got = [None] * 9
+
+    def work(i):
+        got[i] = m.forward_ids(batches[i % 3], want_logp=True)
+    for _ in range(3):
+        run_threads(work, 9)
+        for i, g in enumerate(got):
+            w = want[i % 3]
+            for b in range(4):
+                assert list(g["ids"][b]) == list(w["ids"][b])
+                assert np.array_equal(g["logp"][b], w["logp"][b])           # same kernels, same batch: bit-identical on any context
+    free3 = torch.cuda.mem_get_info()[0]
+    st = m.inflight_stats()
+    assert [s["context"] for s in st] == [0, 1, 2] and all(s["forwards"] > 0 for s in st), st
+    per_extra_context = (free1 - free3) / 2
+    assert per_extra_context < 0.25 * blob.nbytes, (per_extra_context, blob.nbytes)      # a workspace, not a weight copy
+    m.close()
+    torch.cuda.synchronize()
+    # everything given back (the HIP runtime keeps its code objects and scratch: ~0.2 GB that no model owns)
+    assert torch.cuda.mem_get_info()[0] - free3 >= blob.nbytes and torch.cuda.mem_get_info()[0] >= free0 - (512 << 20)
+
+
+@pytest.fixture(scope="module")
+def small(pkg, weights_mod):
+    need_gpu()
+    cfg = weights_mod.small_config(enc_layers=3, dec_layers=2, vocab=400)
+    man, blob = weights_mod.synth_weights(cfg, seed=77)
+    return man, blob
+
+
+def test_one_queue_feeds_idle_contexts_and_a_lone_caller_never_waits(pkg, small):
+    man, blob = small
+    m = pkg.ParaformerHip().InitAsr((man, blob))
+    m.set_inflight(3)
+    m.set_batching(200000, 64)          # a wait far longer than any forward: only ever paid when company is evident
+    rng = np.random.default_rng(11)
+    utts = [synth_pcm(i, int(rng.integers(16000 * 2, 16000 * 9)), rng) for i in range(24)]
+    m.forward_ids([utts[0]])
+    t0 = time.perf_counter()
+    want = [m.forward_ids([u], want_logp=True) for u in utts]
+    per_call = (time.perf_counter() - t0) / len(utts)
+    assert per_call < 0.1, f"a lone caller waited: {per_call * 1e3:.1f} ms per call with wait_us = 200 ms"
+    before = m.inflight_stats()
+    got = [None] * len(utts)
+
+    def work(i):
+        got[i] = m.forward_ids([utts[i]], want_logp=True)
+    run_threads(work, len(utts))
+    after = m.inflight_stats()
+    fw = sum(a["forwards"] - b["forwards"] for a, b in zip(after, before))
+    calls = sum(a["calls"] - b["calls"] for a, b in zip(after, before))
+    assert calls == len(utts) and fw < calls, (fw, calls)                  # merged launches
+    for g, w in zip(got, want):
+        assert list(g["ids"][0]) == list(w["ids"][0])
+        assert np.abs(g["logp"][0] - w["logp"][0]).max() < 1e-4             # other batch composition -> other GEMM tiling, same values
+    m.close()
+
+
+def test_timestamp_model_is_merged_too(pkg, weights_mod):
+    need_gpu()
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=1, vocab=300, timestamp=1)
+    man, blob = weights_mod.synth_weights(cfg, seed=5)
+    m = pkg.ParaformerHip().InitAsr((man, blob))
+    rng = np.random.default_rng(2)
+    utts = [synth_pcm(i, int(rng.integers(16000 * 2, 16000 * 7)), rng) for i in range(10)]
+    want = [m.forward_ids([u], want_timestamps=True) for u in utts]
+    m.set_inflight(2)
+    m.set_batching(20000, 16)
+    before = m.inflight_stats()
+    got = [None] * len(utts)
+
+    def work(i):
+        got[i] = m.forward_ids([utts[i]], want_timestamps=True)
+    run_threads(work, len(utts))
+    after = m.inflight_stats()
+    assert sum(a["forwards"] - b["forwards"] for a, b in zip(after, before)) < len(utts)
+    for g, w in zip(got, want):
+        assert list(g["ids"][0]) == list(w["ids"][0])
+        assert g["us_alphas"][0].shape == w["us_alphas"][0].shape
+        assert np.abs(g["us_alphas"][0] - w["us_alphas"][0]).max() < 1e-4
+        assert np.abs(g["us_peaks"][0] - w["us_peaks"][0]).max() < 1e-3
+    m.close()
+
+
+def test_contextual_calls_with_their_own_hotwords_run_on_separate_contexts(pkg, weights_mod):
+    need_gpu()
+    cfg = weights_mod.small_config(enc_layers=2, dec_layers=2, vocab=400, contextual=1)
+    man, blob = weights_mod.synth_weights(cfg, seed=9)
+    m = pkg.ParaformerHip().InitAsr((man, blob))
+    rng = np.random.default_rng(4)
+    utts = [synth_pcm(i, 16000 * 4 + 999 * i, rng) for i in range(6)]
+    sets = [m.CompileHotwordEmbedding([list(rng.integers(2, 400, n)) for n in (2, 3, 4 + k % 3)]) for k in range(6)]
+    want = [m.forward_ids([u], hw_emb=h, want_logp=True) for u, h in zip(utts, sets)]
+    m.set_inflight(3)
+    m.set_batching(5000, 16)            # contextual calls bypass the queue: hotwords are per connection
+    got = [None] * 6
+
+    def work(i):
+        got[i] = m.forward_ids([utts[i]], hw_emb=sets[i], want_logp=True)
+    for _ in range(3):
+        run_threads(work, 6)
+        for g, w in zip(got, want):
+            assert list(g["ids"][0]) == list(w["ids"][0]) and np.array_equal(g["logp"][0], w["logp"][0])
+    assert sum(s["forwards"] > 0 for s in m.inflight_stats()) >= 2
+    m.close()
+
+
+def test_resident_form_is_routed_like_the_host_form(pkg, small):
+    man, blob = small
+    m = pkg.ParaformerHip().InitAsr((man, blob))
+    m.set_inflight(2)
+    rng = np.random.default_rng(8)
+    utts = [synth_pcm(i, 16000 * 5, rng) for i in range(4)]
+    want = m.forward_ids(utts)
+    d = torch.from_numpy(np.concatenate(utts)).cuda()
+    torch.cuda.synchronize()
+    off = np.arange(4, dtype=np.int64) * 16000 * 5
+    ns = np.full(4, 16000 * 5, np.int32)
+    got = [None] * 4
+
+    def work(i):
+        got[i] = m.forward_resident(d.data_ptr(), off, ns, 16000 * 5 // 960 + 2)
+    run_threads(work, 4)
+    for g in got:
+        assert [list(x) for x in g["ids"]] == [list(x) for x in want["ids"]]
+    assert all(s["forwards"] > 0 for s in m.inflight_stats())
+    m.close()
+
+
+def test_env_var_gives_an_unchanged_caller_its_contexts(tmp_path):
+    code = (
+        "import sys, numpy as np, importlib\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import __graft_entry__ as ge\n"
+        "pkg = ge.load_package(); weights = importlib.import_module('asr_2pass_amd.weights')\n"
+        "man, blob = weights.synth_weights(weights.small_config(enc_layers=1, dec_layers=1, vocab=300), seed=3)\n"
+        "m = pkg.ParaformerHip().InitAsr((man, blob))\n"
+        "print('INFLIGHT', m.get_inflight(), len(m.inflight_stats()))\n")
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, PFHIP_INFLIGHT="4"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "INFLIGHT 4 4" in out.stdout
+
+
+def test_sixteen_decoder_threads_behind_the_default_server_flags(pkg, weights_mod, tmp_path):
+    """The C++ adapter initialised as the unchanged server does with its DEFAULT flags — FunOfflineInit(..., thread_num = 1):
+    --model-thread-num, funasr-wss-server.cpp:105-106,511 — and driven by 16 decoder threads like websocket-server.cpp:387-403
+    (`serve_threads` harness): merged launches (utterances per forward > 1), several contexts used, every result identical
+    to the separate calls."""
+    need_gpu()
+    cfg = weights_mod.small_config(enc_layers=6, dec_layers=3, vocab=300, timestamp=1)
+    man, blob = weights_mod.synth_weights(cfg, seed=21)
+    mdir = tmp_path / "asr"
+    mdir.mkdir()
+    weights_mod.save(str(mdir / "model.pfhip"), man, blob)
+    with open(mdir / "tokens.json", "w") as f:
+        json.dump([f"<{i}>" for i in range(300)], f)
+    exe = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "serve_threads")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PFHIP_")}
+    out = subprocess.run([exe, str(mdir), "-", "16", "96", "2", "9", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["mismatches"] == 0 and r["failures"] == 0 and r["model_thread_num"] == 1 and r["decoder_threads"] == 16
+    assert r["inflight"] == 3 and r["slots"] == 3
+    assert r["separate"]["forwards"] == r["separate"]["calls"] == r["separate"]["utterances"] == 96      # nobody to merge with
+    c = r["concurrent"]
+    assert c["calls"] == c["utterances"] == 96
+    assert c["forwards"] * 1.5 <= c["utterances"], c                     # merged: > 1.5 utterances per packed forward
+    assert r["slots_used"] >= 2, r
+    # --model-thread-num changes nothing (it is the reference's intra-op thread count)
+    out8 = subprocess.run([exe, str(mdir), "-", "16", "48", "2", "9", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert out8.returncode == 0, out8.stderr[-2000:]
+    r8 = json.loads(out8.stdout.strip().splitlines()[-1])
+    assert r8["mismatches"] == 0 and r8["inflight"] == 3 and r8["concurrent"]["forwards"] < r8["concurrent"]["utterances"]
+    # PFHIP_OFFLINE_WAIT_US=0 / PFHIP_INFLIGHT=1 switch both off
+    out0 = subprocess.run([exe, str(mdir), "-", "8", "24", "2", "5", "1"], capture_output=True, text=True, timeout=600,
+                          env=dict(env, PFHIP_OFFLINE_WAIT_US="0", PFHIP_INFLIGHT="1"))
+    assert out0.returncode == 0, out0.stderr[-2000:]
+    r0 = json.loads(out0.stdout.strip().splitlines()[-1])
+    assert r0["inflight"] == 1 and r0["concurrent"]["forwards"] == r0["concurrent"]["utterances"] == 24 and r0["mismatches"] == 0

@@ -250,14 +250,14 @@ def test_gemm_bf16_split_is_fp32_grade(ops):
     ref = A.astype(np.float64) @ W.astype(np.float64).T
     norm = np.sqrt((A.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
     err = {}
-    for kind in (1, 4, 5, 6, 7):
+    for kind in (1, 4, 5, 7):
         C = ops.gemm_f32(dA, dW, M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
         err[kind] = float((np.abs(C - ref) / norm).max())
-    assert err[4] <= 1.5 * err[1] + 1e-9 and err[5] <= 1.5 * err[1] + 1e-9 and err[6] <= 1.5 * err[1] + 1e-9 and err[7] <= 1.5 * err[1] + 1e-9, err
-    assert err[4] < 5e-7 and err[5] < 5e-7 and err[6] < 5e-7 and err[7] < 5e-7, err
+    assert err[4] <= 1.5 * err[1] + 1e-9 and err[5] <= 1.5 * err[1] + 1e-9 and err[7] <= 1.5 * err[1] + 1e-9, err
+    assert err[4] < 5e-7 and err[5] < 5e-7 and err[7] < 5e-7, err
     Ai = rng.integers(-700, 700, (300, 32)).astype(np.float32)                 # 10-bit operands (two planes); sums < 2^24: exact
     Wi = rng.integers(-700, 700, (256, 32)).astype(np.float32)
-    for kind in (4, 5, 6, 7):
+    for kind in (4, 5, 7):
         C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=kind).cpu().numpy()[:300, :256]
         assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))
 
@@ -277,7 +277,7 @@ def test_gemm_bf16_split_stated_domain(ops):
     A[9, 100] = -np.inf
     A[40, 5] = np.nan
     ref = A.astype(np.float64) @ W.astype(np.float64).T
-    for kind in (4, 5, 6, 7):
+    for kind in (4, 5, 7):
         C = ops.gemm_f32(dev(pad_rows(A)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
         for r in (3, 9, 40):
             assert np.isnan(C[r]).all(), (kind, r)                    # the fp32-MFMA kernel gives +-Inf in rows 3 and 9
@@ -293,7 +293,7 @@ def test_gemm_bf16_split_stated_domain(ops):
     A2 = (A2 * scale).astype(np.float32)
     ref2 = A2.astype(np.float64) @ W.astype(np.float64).T
     norm = np.sqrt((A2.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
-    for kind in (4, 5, 6, 7):
+    for kind in (4, 5, 7):
         C = ops.gemm_f32(dev(pad_rows(A2)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=kind).cpu().numpy()[:M, :N]
         rel = np.abs(C - ref2) / norm
         assert rel[:128].max() < 5e-7, (kind, rel[:128].max())

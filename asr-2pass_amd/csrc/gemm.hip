@@ -708,9 +708,40 @@ inline bool prefer_half_tile(int tiles128) {
   return 0.55 * r64 < 0.98 * r128;
 }
 
+// The split-operand kernels: fp16 two-plane / three-product form (gemm_x3.hip, default) or bf16 three-plane / six-product form
+// (gemm_x6.hip: fp32's exponent range; PFHIP_GEMM_X3=0).  PFHIP_X3_SA / PFHIP_X3_SW: log2 of the operand scales of the fp16 form
+// (default 0 / 0: see the scaling note at the top of gemm_x3.hip).
+float best_w_scale(float max_abs) {
+  if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 1.0f;
+  int e = 0;
+  (void)frexpf(32768.0f / max_abs, &e);          // 32768 / max = f * 2^e, f in [0.5, 1): 2^(e-1) <= 32768 / max
+  e = std::max(-8, std::min(20, e - 1));
+  return ldexpf(1.0f, e);                          // max_abs * scale <= 32768 < 65504
+}
+static bool x3_enabled() {
+  static const bool on = [] { const char* e = getenv("PFHIP_GEMM_X3"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static void launch_split_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
+                              int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
+                              const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, int form,
+                              float w_scale) {
+  if (form == 3 || (form == 0 && x3_enabled())) {
+    // PFHIP_X3_SA: log2 of the activation scale (default 0: |a| < 65504, absolute floor 2^-25 per element);
+    // PFHIP_X3_SW: override of the per-tensor weight scale the caller passes (log2)
+    static const float sa = [] { const char* e = getenv("PFHIP_X3_SA"); return ldexpf(1.f, e ? atoi(e) : 0); }();
+    static const float sw_env = [] { const char* e = getenv("PFHIP_X3_SW"); return e ? ldexpf(1.f, atoi(e)) : 0.f; }();
+    launch_gemm_f32_f16x3(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, gw, s, small_tile, ln_stats, ln_tiles, stats_out,
+                          half_tile, ln_colsum, sa, sw_env > 0.f ? sw_env : w_scale);
+    return;
+  }
+  launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, gw, s, small_tile, ln_stats, ln_tiles, stats_out,
+                         half_tile, ln_colsum);
+}
+
 void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                           int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, bool guard, int kind,
-                          hipStream_t s) {
+                          hipStream_t s, float w_scale) {
   if (M <= 0 || N <= 0) return;
   const int tiles = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
   // Launches of at least half a round of tiles go to the BF16 matrix cores (exact three-way split, six MFMAs per block:
@@ -721,15 +752,19 @@ void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, floa
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
   // (tools/gemm_small_probe.py: between 48 and 128 tiles of 128 x 128 the half-height BF16-split kernel beats both the fp32-MFMA
   // 64-row kernel and the 128 x 128 BF16-split kernel by 15-25 % — 1-5 utterances of 30 s, rounds of 25-128 streaming connections)
-  if (kind == 4 || kind == 5 || kind == 7 || (kind == 0 && x6_on && tiles >= 48)) {
+  // kinds 4 / 5 / 7: the bf16 six-product form (256 x 128, 128 x 128, 64 x 128 tile); 8 / 9 / 10: the fp16 three-product form
+  if (kind == 4 || kind == 5 || kind == 7 || kind == 8 || kind == 9 || kind == 10 || (kind == 0 && x6_on && tiles >= 48)) {
+    const int form = kind == 0 ? 0 : (kind >= 8 ? 3 : 6);
+    if (kind >= 8) kind = kind == 8 ? 4 : (kind == 9 ? 5 : 7);
     const bool small_tile = kind == 5 || kind == 7 || (kind == 0 && !(K >= 1024 && tiles256 >= 180));
     // measured (tools/gemm_mid_probe.py, kinds 5 vs 7, N = 512): the half-height tile wins while its own grid still fits one
     // workgroup per CU (<= 128 tiles of 128 x 128 = 256 half tiles: 19.0 vs 22.1 us at M = 4000, K = 512; 61 vs 66 at K = 2048);
     // at 160 tiles (316 half tiles: a second, mostly empty round) the taller tile is ahead again (23.2 vs 27.4, 72 vs 93 us at
     // M = 5000), as at 220 (28.3 vs 31.9 at M = 7015)
     const bool half_tile = kind == 7 || (kind == 0 && small_tile && tiles <= 128);
-    launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                           column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, nullptr, 0, nullptr, half_tile);
+    launch_split_gemm(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
+                      column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, nullptr, 0, nullptr, half_tile, nullptr, form,
+                      w_scale);
     return;
   }
   const bool skinny = kind == 2 || (kind == 0 && tiles < kStreamingBelowTiles);
@@ -760,21 +795,21 @@ bool gemm_x6_ln_ok(int M) {
 }
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
-                           const float* ln_colsum, float* stats_out, hipStream_t s) {
+                           const float* ln_colsum, float* stats_out, hipStream_t s, float w_scale) {
   if (M <= 0 || N <= 0) return;
   const int tiles256 = ((M + 255) / 256) * ((N + kTileN - 1) / kTileN);
   const bool small_tile = !(K >= 1024 && tiles256 >= 180);
   const int tiles128 = ((M + kTileM - 1) / kTileM) * ((N + kTileN - 1) / kTileN);
   const bool half_tile = small_tile && tiles128 <= 128;       // as the default dispatch: 64-row tiles where 128-row ones leave CUs idle
-  launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
-                         column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out, half_tile,
-                         ln_colsum);
+  launch_split_gemm(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu,
+                    column_group_width(M, K, (N + kTileN - 1) / kTileN), s, small_tile, ln_stats, ln_tiles, stats_out, half_tile,
+                    ln_colsum, 0, w_scale);
 }
 
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2, int M,
-                     int N, int K, bool relu, bool guard, hipStream_t s) {
-  launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, guard, 0, s);
+                     int N, int K, bool relu, bool guard, hipStream_t s, float w_scale) {
+  launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, guard, 0, s, w_scale);
 }
 
 }  // namespace pfhip

@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pfhip.h"
@@ -78,12 +79,15 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // A linear layer repacked for the GEMM kernels: W zero-padded to [ceil(N/128)*128][ceil(K/32)*32], bias to the
 // padded N, so pad outputs are exact zeros (odd widths: FSMN-VAD 140/250/248, punctuation head 6).
-struct Lin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0, Np = 0, Kp = 0; };
+struct Lin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0, Np = 0, Kp = 0; float ws = 1.0f; };
 inline pfhip_status pack_linear(const float* w, const float* bias, int N, int K, Lin* out) {
   out->N = N; out->K = K; out->Np = round_up(N, 128); out->Kp = round_up(K, 32);
   std::vector<float> pw((size_t)out->Np * out->Kp, 0.f), pb((size_t)out->Np, 0.f);
   for (int n = 0; n < N; ++n) std::memcpy(&pw[(size_t)n * out->Kp], w + (size_t)n * K, sizeof(float) * K);
   if (bias) std::memcpy(pb.data(), bias, sizeof(float) * N);
+  float mx = 0.f;
+  for (float v : pw) mx = std::max(mx, std::fabs(v));
+  out->ws = pfhip::best_w_scale(mx);
   HIP_TRY(hipMalloc((void**)&out->w, pw.size() * 4));
   HIP_TRY(hipMemcpy(out->w, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&out->b, pb.size() * 4));
@@ -92,7 +96,7 @@ inline pfhip_status pack_linear(const float* w, const float* bias, int N, int K,
 }
 inline void lin_gemm(hipStream_t s, const Lin& l, const float* A, int lda, float* C, int ldc, const float* R1, int ldr1,
                      const float* R2, int ldr2, int M, bool relu) {
-  pfhip::launch_gemm_f32(A, lda, l.w, l.Kp, C, ldc, l.b, R1, ldr1, R2, ldr2, M, l.Np, l.Kp, relu, false, s);
+  pfhip::launch_gemm_f32(A, lda, l.w, l.Kp, C, ldc, l.b, R1, ldr1, R2, ldr2, M, l.Np, l.Kp, relu, false, s, l.ws);
 }
 inline void free_lin(Lin& l) { if (l.w) (void)hipFree(l.w); if (l.b) (void)hipFree(l.b); l.w = l.b = nullptr; }
 
@@ -207,6 +211,11 @@ struct pfhip_model {
   std::vector<pfhip_model*> slots;          // on the head: every execution slot of the handle, device-major round order; guarded by bq.mu
   std::vector<float> hw_host;               // on the head: the resident hotword set (pfhip_set_hotwords), for contexts created later
 
+  // per weight matrix (device pointer of its first element): the power-of-two scale the fp16 two-plane GEMM stages it with
+  // (kernels.h best_w_scale), fixed at load from its largest magnitude; contexts copy the table
+  std::unordered_map<const void*, float> wscale;
+  float w_scale_of(const void* w) const { auto it = wscale.find(w); return it == wscale.end() ? 1.0f : it->second; }
+
   const Tensor& W(const std::string& n) const { return t.at(n); }
 };
 
@@ -247,7 +256,7 @@ inline void gemm(pfhip_model* m, hipStream_t s, const float* A, int lda, const f
           float* C, int ldc, const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
           int M, bool relu) {
   Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * Ktrue, 4.0 * ((double)M * Ktrue + (double)N * Ktrue + (double)M * N));
-  launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, /*guard=*/false, s);
+  launch_gemm_f32(A, lda, Wd, K, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, /*guard=*/false, s, m->w_scale_of(Wd));
 }
 // pinned staging, grown on demand (callers have no copy in flight from the old block: every forward ends with a sync)
 inline pfhip_status ensure_h_meta(pfhip_model* m, size_t bytes) {

@@ -49,7 +49,10 @@ void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_
 // C may alias R1 or R2 (in-place residual update).
 void launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
                      const float* bias, const float* R1, int ldr1, const float* R2, int ldr2,
-                     int M, int N, int K, bool relu, bool guard, hipStream_t s);
+                     int M, int N, int K, bool relu, bool guard, hipStream_t s, float w_scale = 1.0f);
+// w_scale: power of two with max|W| * w_scale < 65504, used by the fp16 two-plane kernels (gemm_x3.hip) to stage W * w_scale
+// (best_w_scale below; 1 is always valid for |W| < 65504 and costs precision only for weights of very small magnitude)
+float best_w_scale(float max_abs);
 // kind: 0 = pick by M, 1 = the 128 x 128 tiled kernel, 2 = the weight-streaming kernel (dev / tests)
 // fp32-grade GEMM on the BF16 matrix cores (three-way bf16 split of both operands, six MFMAs per block): gemm_x6.hip
 // stats_out (N == tiles_n * 128 exactly): the epilogue also leaves per-row LayerNorm statistics of its 128-column tile at
@@ -61,16 +64,20 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile = false,
                             const float* ln_stats = nullptr, int ln_tiles = 0, float* stats_out = nullptr, bool half_tile = false,
                             const float* ln_colsum = nullptr);
+// the same tilings with TWO fp16 planes and THREE products per block (gemm_x3.hip); sa / sw: power-of-two operand scales
+void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
+                           int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
+                           const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, float sa, float sw);
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).
 bool gemm_x6_ln_ok(int M);
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
-                           const float* ln_colsum, float* stats_out, hipStream_t s);
+                           const float* ln_colsum, float* stats_out, hipStream_t s, float w_scale = 1.0f);
 void launch_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                           int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, bool guard, int kind,
-                          hipStream_t s);
+                          hipStream_t s, float w_scale = 1.0f);
 
 // y[row][0..D) = LN(x[row][0..D)) * g + b; columns D..Dout zeroed.  D % 4 == 0, Dout <= 2048.
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,

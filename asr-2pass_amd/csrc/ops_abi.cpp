@@ -20,7 +20,7 @@ int pfhip_op_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C
 int pfhip_op_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                            const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
                            int guard, int kind, void* stream) {
-  if (K % pfhip::kTileK || kind < 0 || kind > 7) return (int)hipErrorInvalidValue;
+  if (K % pfhip::kTileK || kind < 0 || kind > 10 || kind == 6) return (int)hipErrorInvalidValue;
   pfhip::launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu != 0, guard != 0, kind, S(stream));
   return done();
 }
@@ -70,6 +70,15 @@ int pfhip_op_fused_att_out(const float* Q, int ldq, const float* K, int ldk, con
     return (int)hipErrorInvalidValue;
   return done();
 }
+int pfhip_op_gemm_f32_scaled(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
+                             int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu, int guard, int kind, float w_scale,
+                             void* stream) {
+  if (K % pfhip::kTileK || kind < 0 || kind > 10 || kind == 6 || !(w_scale > 0.f)) return (int)hipErrorInvalidValue;
+  pfhip::launch_gemm_f32_kind(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu != 0, guard != 0, kind, S(stream), w_scale);
+  return (int)hipGetLastError();
+}
+float pfhip_op_best_w_scale(float max_abs) { return pfhip::best_w_scale(max_abs); }
+
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream) {
   if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;

@@ -183,6 +183,14 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     tt.h = hb + off / 4;
     m->t.emplace(kv.first, std::move(tt));
   }
+  // fp16 two-plane GEMM (gemm_x3.hip): one power-of-two scale per weight matrix, from its largest magnitude
+  auto reg_scale = [&](const void* dptr, const float* host, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(host[i]));
+    m->wscale[dptr] = pfhip::best_w_scale(mx);
+  };
+  for (const auto& kv : m->t)
+    if (kv.second.shape.size() >= 2) reg_scale(kv.second.d, kv.second.h, kv.second.n);
   // required tensors / shapes
   auto need = [&](const std::string& n, std::vector<int> shape) -> bool {
     auto it = m->t.find(n);
@@ -240,6 +248,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
       std::memcpy(&p[(size_t)n * m->feat_pad], w0.h + (size_t)n * m->feat_dim, sizeof(float) * m->feat_dim);
     pfhip_status st = upload(&m->d_w0qkv, p);
     if (st) return st;
+    reg_scale(m->d_w0qkv, p.data(), p.size());
     const Tensor& cw = m->W("pred.conv.w");
     std::vector<float> q((size_t)d * 3 * d);
     for (int n = 0; n < d; ++n)
@@ -247,6 +256,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
         for (int j = 0; j < 3; ++j) q[(size_t)n * 3 * d + (size_t)j * d + ci] = cw.h[((size_t)n * d + ci) * 3 + j];
     st = upload(&m->d_predconv, q);
     if (st) return st;
+    reg_scale(m->d_predconv, q.data(), q.size());
     if (d == 4 * pfhip::kTileN) {   // LN-on-load needs the residual stream to be exactly four 128-column tiles wide
       // W' = W * gamma[k], b' = b + W beta: LayerNorm's affine part folded into the GEMM that consumes it (offline path,
       // large batches: enqueue_locked).  Products in double, rounded once.
@@ -283,6 +293,11 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
       if (!st) st = upload(&m->d_lnb_ffn1, bf);
       if (!st) st = upload(&m->d_lns_qkv, sq);
       if (!st) st = upload(&m->d_lns_ffn1, sf);
+      if (st) return st;
+      for (int i = 0; i < L; ++i) {
+        reg_scale(m->d_lnw_qkv + (size_t)i * 3 * d * d, &wq[(size_t)i * 3 * d * d], (size_t)3 * d * d);
+        reg_scale(m->d_lnw_ffn1 + (size_t)i * c.ffn * d, &wf[(size_t)i * c.ffn * d], (size_t)c.ffn * d);
+      }
       if (!st && c.dec_ffn % pfhip::kTileN == 0) {          // decoder FFNs: layers 0..dec_layers-1 and dec3 (the last entry)
         const int DL = c.dec_layers + 1, f = c.dec_ffn;
         std::vector<float> w1((size_t)DL * f * d + (size_t)pfhip::kTileN * d, 0.f), b1((size_t)DL * f + pfhip::kTileN, 0.f), s1(b1.size(), 0.f);
@@ -304,6 +319,12 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
         if (!st) st = upload(&m->d_dlnw2, w2);
         if (!st) st = upload(&m->d_dlnb2, b2);
         if (!st) st = upload(&m->d_dlns2, s2);
+        if (st) return st;
+        for (int i = 0; i < DL; ++i) {
+          reg_scale(m->d_dlnw1 + (size_t)i * f * d, &w1[(size_t)i * f * d], (size_t)f * d);
+          reg_scale(m->d_dlnw2 + (size_t)i * d * f, &w2[(size_t)i * d * f], (size_t)d * f);
+          reg_scale(m->d_dlnw3 + (size_t)i * d * d, &w3[(size_t)i * d * d], (size_t)d * d);
+        }
       }
       if (st) return st;
     }
@@ -317,6 +338,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
       st = upload(&m->d_kv_all_w, kw);
       if (!st) st = upload(&m->d_kv_all_b, kb);
       if (st) return st;
+      reg_scale(m->d_kv_all_w, kw.data(), kw.size());
     }
     std::vector<float> vb((size_t)m->vocab_pad, 0.f);
     std::memcpy(vb.data(), m->W("dec.out.b").h, sizeof(float) * c.vocab);
@@ -334,6 +356,8 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     for (int j = 0; j < 3; ++j) std::memcpy(&b2[(size_t)j * d], m->W("pred.up.b").h, sizeof(float) * d);
     pfhip_status st = upload(&m->d_up_w, w2);
     if (!st) st = upload(&m->d_up_b, b2);
+    if (st) return st;
+    reg_scale(m->d_up_w, w2.data(), w2.size());
     // both directions' input projections in one GEMM (N = 8d), b_ih + b_hh folded; recurrent weights [2][4d][d]
     std::vector<float> wih((size_t)8 * d * d), bih((size_t)8 * d), whh((size_t)8 * d * d);
     int dir = 0;
@@ -349,6 +373,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     if (!st) st = upload(&m->d_bih, bih);
     if (!st) st = upload(&m->d_whh, whh);
     if (st) return st;
+    reg_scale(m->d_wih, wih.data(), wih.size());
     m->out2_b = m->W("pred.out2.b").h[0];
   }
   // ---- front-end tables ------------------------------------------------------------------------------
@@ -400,6 +425,7 @@ pfhip_status build_context(pfhip_model* owner, pfhip_model** out) {
   m->cfg = owner->cfg;
   m->feat_dim = owner->feat_dim; m->feat_pad = owner->feat_pad; m->vocab_pad = owner->vocab_pad;
   m->t = owner->t;
+  m->wscale = owner->wscale;
   m->out2_b = owner->out2_b;
 #define X(f) m->f = owner->f;
   PFHIP_WEIGHT_PTRS(X)
@@ -524,7 +550,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
                      bool relu, const float* ln_colsum, bool stats_out, int K) {
     Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, ldc, bias, R1, d, R2, d, M, N, K, relu, ln_colsum ? m->lnstats.f() : nullptr, 4,
-                                 ln_colsum, stats_out ? m->lnstats.f() : nullptr, s);
+                                 ln_colsum, stats_out ? m->lnstats.f() : nullptr, s, m->w_scale_of(Wd));
   };
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
@@ -673,7 +699,8 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   auto x6ln = [&](const float* A, int K, const float* Wd, int N, float* Cd, const float* bias, const float* R1, bool relu,
                   const float* st_in, int tiles_in, const float* colsum, float* st_out) {
     Scope sc(m, s, K_GEMM, 2.0 * ML * (double)N * K, 4.0 * ((double)ML * K + (double)N * K + (double)ML * N));
-    pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, N, bias, R1, d, nullptr, 0, ML, N, K, relu, st_in, tiles_in, colsum, st_out, s);
+    pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, N, bias, R1, d, nullptr, 0, ML, N, K, relu, st_in, tiles_in, colsum, st_out, s,
+                                 m->w_scale_of(Wd));
   };
   bool xd_has_stats = false;          // lnstats holds the row statistics of the current xd
   auto dec_ffn = [&](const std::string& p, int li, const float* xin, float* out) {

@@ -322,7 +322,8 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     // (pfhip.cpp enqueue_locked: row statistics from the producing epilogue, algebraic normalisation in the consumer's)
     if (fuse_ln_s && !first)
       pfhip::launch_gemm_f32_x6_ln(x, d, m->d_lnw_qkv + (size_t)i * 3 * d * d, d, m->qkv.f(), 3 * d, m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, 0,
-                                   nullptr, 0, M, 3 * d, d, false, m->lnstats.f(), 4, m->d_lns_qkv + (size_t)i * 3 * d, nullptr, st);
+                                   nullptr, 0, M, 3 * d, d, false, m->lnstats.f(), 4, m->d_lns_qkv + (size_t)i * 3 * d, nullptr, st,
+                                   m->w_scale_of(m->d_lnw_qkv + (size_t)i * 3 * d * d));
     else {
       lnorm(m, st, xin, ldin, m->y.f(), Kp, p + "norm1", M, Din, Kp);
       gemm(m, st, m->y.f(), Kp, first ? m->d_w0qkv : m->W(p + "qkv.w").d, 3 * d, Kp, Din, m->qkv.f(), 3 * d,
@@ -339,11 +340,13 @@ pfhip_status forward_windows(pfhip_model* m, const std::vector<pfhip_stream*>& s
     }
     if (fuse_ln_s) {
       pfhip::launch_gemm_f32_x6_ln(m->ctx.f(), d, m->W(p + "out.w").d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d, first ? nullptr : x, d, M,
-                                   d, d, false, nullptr, 4, nullptr, m->lnstats.f(), st);
+                                   d, d, false, nullptr, 4, nullptr, m->lnstats.f(), st, m->w_scale_of(m->W(p + "out.w").d));
       pfhip::launch_gemm_f32_x6_ln(x, d, m->d_lnw_ffn1 + (size_t)i * c.ffn * d, d, m->hbuf.f(), c.ffn, m->d_lnb_ffn1 + (size_t)i * c.ffn,
-                                   nullptr, 0, nullptr, 0, M, c.ffn, d, true, m->lnstats.f(), 4, m->d_lns_ffn1 + (size_t)i * c.ffn, nullptr, st);
+                                   nullptr, 0, nullptr, 0, M, c.ffn, d, true, m->lnstats.f(), 4, m->d_lns_ffn1 + (size_t)i * c.ffn, nullptr, st,
+                                   m->w_scale_of(m->d_lnw_ffn1 + (size_t)i * c.ffn * d));
       pfhip::launch_gemm_f32_x6_ln(m->hbuf.f(), c.ffn, m->W(p + "ffn2.w").d, c.ffn, x, d, m->W(p + "ffn2.b").d, x, d, nullptr, 0, M, d, c.ffn,
-                                   false, nullptr, 4, nullptr, i + 1 < c.enc_layers ? m->lnstats.f() : nullptr, st);
+                                   false, nullptr, 4, nullptr, i + 1 < c.enc_layers ? m->lnstats.f() : nullptr, st,
+                                   m->w_scale_of(m->W(p + "ffn2.w").d));
       continue;
     }
     gemm(m, st, m->ctx.f(), d, m->W(p + "out.w").d, d, d, d, x, d, m->W(p + "out.b").d, m->mem.f(), d,

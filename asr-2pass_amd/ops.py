@@ -59,14 +59,33 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
-def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guard=True, out=None, kind=0):
+def best_w_scale(max_abs):
+    lib = _lib()
+    lib.pfhip_op_best_w_scale.restype = ctypes.c_float
+    lib.pfhip_op_best_w_scale.argtypes = [ctypes.c_float]
+    return float(lib.pfhip_op_best_w_scale(float(max_abs)))
+
+
+def gemm_f32(A, W, bias=None, R1=None, R2=None, relu=False, M=None, N=None, guard=True, out=None, kind=0, w_scale=None):
     """C[M,N] = A[M,K] @ W[N,K]^T (+bias +R1 +R2, ReLU).  A must have ceil(M/128)*128 rows allocated
-    and W ceil(N/128)*128 rows; K % 32 == 0."""
+    and W ceil(N/128)*128 rows; K % 32 == 0.  w_scale: the power-of-two weight scale of the fp16 two-plane kernels
+    ("auto" = best_w_scale(max |W|), what the model does per weight matrix at load; None = 1)."""
     K = A.shape[1]
     M = A.shape[0] if M is None else M
     N = W.shape[0] if N is None else N
     if out is None:
         out = torch.empty((round_up(M, 128), round_up(N, 128)), dtype=torch.float32, device=A.device)
+    if w_scale is not None:
+        if w_scale == "auto":
+            w_scale = best_w_scale(float(W.abs().max()))
+        lib = _lib()
+        lib.pfhip_op_gemm_f32_scaled.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci,
+                                                 ctypes.c_float, _vp]
+        _ck(lib.pfhip_op_gemm_f32_scaled(_p(A), A.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias),
+                                         _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
+                                         R2.stride(0) if R2 is not None else 0, M, N, K, 1 if relu else 0,
+                                         1 if guard else 0, kind, float(w_scale), _stream()), "gemm")
+        return out
     _ck(_lib().pfhip_op_gemm_f32_kind(_p(A), A.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias),
                                       _p(R1), R1.stride(0) if R1 is not None else 0, _p(R2),
                                       R2.stride(0) if R2 is not None else 0, M, N, K, 1 if relu else 0,

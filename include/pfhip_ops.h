@@ -17,10 +17,17 @@ extern "C" {
 int pfhip_op_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                       const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
                       int guard, void* stream);
-/* Same, with the kernel forced: kind 0 = by size (as above), 1 = 128x128 tiled, 2 = weight-streaming (M-small) kernel. */
+/* Same, with the kernel forced: kind 0 = by size (as above), 1 = 128x128 tiled, 2 = weight-streaming (M-small) kernel,
+ * 3 = 64x128 tiled; 4 / 5 / 7 = bf16 three-plane kernels (256x128, 128x128, 64x128 tile); 8 / 9 / 10 = fp16 two-plane kernels. */
 int pfhip_op_gemm_f32_kind(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                            const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
                            int guard, int kind, void* stream);
+/* Same; w_scale = the power-of-two scale the fp16 two-plane kernels (kinds 8 / 9 / 10, and kind 0 by default) stage W with:
+ * pfhip_op_best_w_scale(max |W|) keeps max |W| * w_scale <= 32768 (the model does this per weight matrix at load). */
+int pfhip_op_gemm_f32_scaled(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                             const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int relu,
+                             int guard, int kind, float w_scale, void* stream);
+float pfhip_op_best_w_scale(float max_abs);
 /* LayerNormalization over the last axis. */
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream);

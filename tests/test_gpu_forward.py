@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import synth_pcm
+from conftest import assert_ids_match, synth_pcm
 from oracle import frontend as fe
 from oracle import paraformer as P
 
@@ -224,7 +224,7 @@ def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod
             ref = P.forward_pcm(u, W)
             assert np.abs(enc[o:o + T] - ref["enc"]).max() < 2e-4, i
             assert int(got["token_num"][i]) == ref["token_num"]
-            assert list(got["ids"][i]) == list(ref["ids"])
+            assert_ids_match(got["ids"][i], ref)          # utterance 4 of the 5-utterance case has a 1.2e-5 tie at row 101
             assert np.abs(got["logp"][i] - ref["logp"]).max() < 1e-3
         o += T
     model.close()

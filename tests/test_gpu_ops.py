@@ -33,7 +33,7 @@ def pad_rows(a, m=128):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 32), (128, 128, 32), (130, 512, 512), (500, 1536, 576),
                                    (257, 1003, 512), (16, 512, 2048), (1000, 2048, 512)])
 @pytest.mark.parametrize("guard", [True, False])
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5])    # by size / 128x128 / weight-streaming / 64x128 / bf16 split 256x128, 128x128
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 8, 9, 10])    # by size / 128x128 / weight-streaming / 64x128 / bf16 split 256x128, 128x128 / fp16 split 256x128, 128x128, 64x128
 def test_gemm_matches_numpy(ops, M, N, K, guard, kind):
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -232,7 +232,7 @@ def test_gemm_random_shapes_all_kernels(ops):
         dbias = dev(np.concatenate([bias, np.zeros(Np - N, np.float32)]))
         dR1 = dev(np.pad(pad_rows(R1), ((0, 0), (0, Np - N))))
         ref = np.maximum(A @ W.T + bias + R1, 0)
-        for kind in (1, 2, 3, 4, 5):
+        for kind in (1, 2, 3, 4, 5, 7, 8, 9, 10):
             C = ops.gemm_f32(dA, dW, bias=dbias, R1=dR1, relu=True, M=M, N=N, guard=True, kind=kind).cpu().numpy()
             assert np.abs(C[:M, :N] - ref).max() < 3e-5 * max(1.0, np.sqrt(K / 512)), (M, N, K, kind)
 
@@ -260,6 +260,83 @@ def test_gemm_bf16_split_is_fp32_grade(ops):
     for kind in (4, 5, 7):
         C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=kind).cpu().numpy()[:300, :256]
         assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))
+
+
+def test_gemm_f16_split_is_fp32_grade(ops):
+    """The fp16 two-plane kernels (gemm_x3.hip: x = hi + lo in fp16, THREE products per block) against an fp64 reference, with
+    the weight scale the model fixes per matrix at load (best_w_scale): the operands keep 22-23 significant bits, which is below
+    what an fp32 accumulation chain of the same length commits — on rows of O(1) the error is that of the fp32 MFMA kernel
+    (x 1.5).  Activations are staged unscaled: an ABSOLUTE floor of 2^-25 per element, so rows of small norm keep the absolute
+    accuracy of O(1) rows, not their own relative one (second half).  One-plane integers come out exact."""
+    rng = np.random.default_rng(15)
+    M, N, K = 700, 384, 1024
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    dA, dW = dev(pad_rows(A)), dev(pad_rows(W))
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    norm = np.sqrt((A.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
+    err, rms = {}, {}
+    for kind in (1, 4, 8, 9, 10):
+        C = ops.gemm_f32(dA, dW, M=M, N=N, guard=True, kind=kind, w_scale="auto").cpu().numpy()[:M, :N]
+        err[kind] = float((np.abs(C - ref) / norm).max())
+        rms[kind] = float(np.sqrt((((C - ref) / norm) ** 2).mean()))
+    for kind in (8, 9, 10):
+        assert rms[kind] <= 1.5 * rms[1] + 1e-9 and err[kind] <= 1.5 * err[1] + 1e-9 and err[kind] < 5e-7, (err, rms)
+    # unscaled weights of this magnitude (row norm 1, elements ~0.03) sit on the fp16 floor: still within 3 x the fp32 kernel
+    C1 = ops.gemm_f32(dA, dW, M=M, N=N, guard=True, kind=9).cpu().numpy()[:M, :N]
+    assert np.sqrt((((C1 - ref) / norm) ** 2).mean()) <= 3.0 * rms[1], rms
+    # rows from 2^-7 to 2^7: the absolute error of a row stays what it is for an O(1) row (floor 2^-25 per element)
+    scale_a = np.exp2(rng.integers(-7, 8, (M, 1))).astype(np.float32)
+    A2 = (A * scale_a).astype(np.float32)
+    ref2 = A2.astype(np.float64) @ W.astype(np.float64).T
+    wn = np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
+    for kind in (8, 9, 10):
+        C = ops.gemm_f32(dev(pad_rows(A2)), dW, M=M, N=N, guard=True, kind=kind, w_scale="auto").cpu().numpy()[:M, :N]
+        abs_err = np.abs(C - ref2) / wn
+        big = (scale_a[:, 0] >= 1)
+        assert (abs_err[big] / (np.sqrt(K) * scale_a[big])).max() < 5e-7             # O(1) and larger rows: relative to their norm
+        assert abs_err[~big].max() < 5e-7 * np.sqrt(K), abs_err[~big].max()          # smaller rows: the absolute bound of an O(1) row
+    Ai = rng.integers(-1000, 1000, (300, 32)).astype(np.float32)               # 10-bit operands: one plane; sums < 2^24: exact
+    Wi = rng.integers(-1000, 1000, (256, 32)).astype(np.float32)
+    for kind in (8, 9, 10):
+        for ws in (None, "auto"):
+            C = ops.gemm_f32(dev(pad_rows(Ai)), dev(pad_rows(Wi)), M=300, N=256, guard=True, kind=kind, w_scale=ws).cpu().numpy()[:300, :256]
+            assert np.array_equal(C, (Ai.astype(np.float64) @ Wi.astype(np.float64).T).astype(np.float32))
+
+
+def test_gemm_f16_split_stated_domain(ops):
+    """Where the fp16 form stops being an fp32 GEMM, pinned (the scaling note at the top of gemm_x3.hip):
+      * |a| >= 65504 (or +-Inf): the high plane saturates and the low plane overflows — EVERY output of that row is Inf or NaN,
+        a loud failure (the bf16 form is exact for any finite magnitude and gives NaN rows for Inf); NaN stays NaN; other rows
+        are untouched;
+      * small magnitudes: absolute floor 2^-25 per element: rows of magnitude 2^-10 keep ~14 bits, rows at 2^-4 are fp32-grade.
+    LayerNorm-ed activations, residual streams and weights of O(1e-3 .. 1e3) are inside; callers outside it use PFHIP_GEMM_X3=0."""
+    rng = np.random.default_rng(16)
+    M, N, K = 256, 256, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    A[3, 17] = 1e6
+    A[9, 100] = -np.inf
+    A[40, 5] = np.nan
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    for kind in (8, 9, 10):
+        C = ops.gemm_f32(dev(pad_rows(A)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=kind, w_scale="auto").cpu().numpy()[:M, :N]
+        # the high plane saturates at 65504, the low plane (round to nearest) overflows: the row fails LOUDLY (Inf / NaN)
+        assert not np.isfinite(C[3]).any() and not np.isfinite(C[9]).any() and np.isnan(C[40]).all(), kind
+        ok = [r for r in range(M) if r not in (3, 9, 40)]
+        assert np.isfinite(C[ok]).all() and np.abs(C[ok] - ref[ok]).max() < 3e-5, kind
+    A2 = rng.standard_normal((M, K)).astype(np.float32)
+    scale = np.ones((M, 1), np.float32)
+    scale[:128] = np.float32(2.0 ** -4)
+    scale[128:] = np.float32(2.0 ** -10)
+    A2 = (A2 * scale).astype(np.float32)
+    ref2 = A2.astype(np.float64) @ W.astype(np.float64).T
+    norm = np.sqrt((A2.astype(np.float64) ** 2).sum(1, keepdims=True)) * np.sqrt((W.astype(np.float64) ** 2).sum(1))[None, :]
+    for kind in (8, 9, 10):
+        C = ops.gemm_f32(dev(pad_rows(A2)), dev(pad_rows(W)), M=M, N=N, guard=True, kind=kind, w_scale="auto").cpu().numpy()[:M, :N]
+        rel = np.abs(C - ref2) / norm
+        assert rel[:128].max() < 5e-7, (kind, rel[:128].max())
+        assert rel[128:].max() < 2.0 ** -13, (kind, rel[128:].max())
 
 
 def test_gemm_bf16_split_stated_domain(ops):

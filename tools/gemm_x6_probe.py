@@ -24,12 +24,13 @@ for (M, N, K) in shapes:
     C = {k: torch.empty(Mp, Np, device="cuda") for k in kinds}
     ref = (A[:M].double() @ W[:N].double().T + b.double() + R[:M, :N].double()).clamp_min(0)
     ts = {k: [] for k in kinds}
+    ws = ops.best_w_scale(float(W.abs().max()))
     for r in range(10):
         for k in kinds:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.gemm_f32(A, W, bias=b, R1=R, relu=True, out=C[k], M=M, N=N, guard=True, kind=k)
+                ops.gemm_f32(A, W, bias=b, R1=R, relu=True, out=C[k], M=M, N=N, guard=True, kind=k, w_scale=(ws if k >= 8 else None))
             e1.record(); torch.cuda.synchronize()
             ts[k].append(e0.elapsed_time(e1) / 5)
     line = f"M={M:5d} N={N:5d} K={K:5d}:"

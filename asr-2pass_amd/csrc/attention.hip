@@ -290,6 +290,17 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
                        kv_len, q_kv_limit, scale);
 }
 
+// the split-operand attention: two fp16 planes / three products (attention_x3.hip, default) or three bf16 planes / six products
+// (attention_x6.hip, PFHIP_ATT_X3=0)
+static void launch_attention_split(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                                   const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
+                                   float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0,
+                                   bool mem_accumulate = false) {
+  static const bool x3 = [] { const char* e = getenv("PFHIP_ATT_X3"); return !(e && e[0] == '0'); }();
+  if (x3) launch_attention_x3(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
+  else launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
+}
+
 static bool att_x6_on() {
   static const bool x6 = [] { const char* e = getenv("PFHIP_ATT_X6"); return !(e && e[0] == '0'); }();
   return x6;
@@ -305,7 +316,7 @@ void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, con
                            int ldmem, hipStream_t s, bool mem_accumulate) {
   if (B <= 0 || max_len <= 0) return;
   if (attention_fsmn_is_fused(max_len)) {
-    launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
+    launch_attention_split(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
     return;
   }
   launch_fsmn(V, ldv, fsmn_w, nullptr, 0, mem, ldmem, off, len, B, max_len, H * kHeadDim, s);
@@ -320,7 +331,7 @@ void launch_attention_hd(const float* Q, int ldq, const float* K, int ldk, const
   // cores with the exact three-way split (attention_x6.hip) — 1.5 x this file's fp32-MFMA kernel.  PFHIP_ATT_X6=0 keeps fp32.
   static const bool x6 = [] { const char* e = getenv("PFHIP_ATT_X6"); return !(e && e[0] == '0'); }();
   if (x6 && head_dim == 128 && max_q_len > 64) {      // streaming windows (20 queries) would leave 7 of its 8 waves idle
-    launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s);
+    launch_attention_split(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s);
     return;
   }
   const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(256);

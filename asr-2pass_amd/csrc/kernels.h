@@ -112,6 +112,11 @@ void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
                          float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0,
                          bool mem_accumulate = false);
+// the same with two fp16 planes and three products per block (attention_x3.hip)
+void launch_attention_x3(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
+                         float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0,
+                         bool mem_accumulate = false);
 // Encoder-layer pair: FSMN memory of V (into mem) + self-attention (into O).  One launch where the BF16 attention kernel runs
 // (d_k = 128, more than 64 queries per utterance), otherwise launch_fsmn + launch_attention.  C = V's channel count (H * 128).
 void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,

@@ -392,6 +392,22 @@ def test_fp32_mfma_kernels_behind_the_opt_out_knobs():
     assert " passed" in out.stdout
 
 
+def test_bf16_six_product_forms_behind_their_knobs():
+    """PFHIP_GEMM_X3=0 / PFHIP_ATT_X3=0 keep the large launches on the three-plane bf16 kernels (gemm_x6.hip, attention_x6.hip:
+    fp32's exponent range) — the form every round-2 result was measured on; the attention cases and the model-level comparisons
+    with the oracle must pass there too (child process: the knobs are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PFHIP_ATT_X3="0", PFHIP_GEMM_X3="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_ops.py", "tests/test_gpu_forward.py",
+                          "-k", "attention_self or attention_cross or attention_rescale or full_size_batch_matches_oracle or layernorm_folded"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 @pytest.mark.parametrize("M,N,K,D,ln,fsmn", [(20, 1536, 512, 512, True, False), (20, 1536, 576, 560, True, False), (20, 512, 512, 512, False, True),
                                               (1, 512, 2048, 2048, True, False), (7, 2048, 512, 512, True, False), (32, 512, 2048, 2048, False, False),
                                               (13, 8404, 512, 512, True, False), (20, 16384, 512, 512, False, False), (9, 1003, 512, 512, True, False)])

@@ -709,8 +709,7 @@ inline bool prefer_half_tile(int tiles128) {
 }
 
 // The split-operand kernels: fp16 two-plane / three-product form (gemm_x3.hip, default) or bf16 three-plane / six-product form
-// (gemm_x6.hip: fp32's exponent range; PFHIP_GEMM_X3=0).  PFHIP_X3_SA / PFHIP_X3_SW: log2 of the operand scales of the fp16 form
-// (default 0 / 0: see the scaling note at the top of gemm_x3.hip).
+// (gemm_x6.hip: fp32's exponent range; PFHIP_GEMM_X3=0).
 float best_w_scale(float max_abs) {
   if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 1.0f;
   int e = 0;
@@ -727,12 +726,10 @@ static void launch_split_gemm(const float* A, int lda, const float* W, int ldw, 
                               const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, int form,
                               float w_scale) {
   if (form == 3 || (form == 0 && x3_enabled())) {
-    // PFHIP_X3_SA: log2 of the activation scale (default 0: |a| < 65504, absolute floor 2^-25 per element);
     // PFHIP_X3_SW: override of the per-tensor weight scale the caller passes (log2)
-    static const float sa = [] { const char* e = getenv("PFHIP_X3_SA"); return ldexpf(1.f, e ? atoi(e) : 0); }();
     static const float sw_env = [] { const char* e = getenv("PFHIP_X3_SW"); return e ? ldexpf(1.f, atoi(e)) : 0.f; }();
     launch_gemm_f32_f16x3(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, gw, s, small_tile, ln_stats, ln_tiles, stats_out,
-                          half_tile, ln_colsum, sa, sw_env > 0.f ? sw_env : w_scale);
+                          half_tile, ln_colsum, sw_env > 0.f ? sw_env : w_scale);
     return;
   }
   launch_gemm_f32_bf16x6(A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, relu, gw, s, small_tile, ln_stats, ln_tiles, stats_out,

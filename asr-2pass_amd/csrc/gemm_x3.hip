@@ -12,9 +12,9 @@
 // (tests/test_gpu_ops.py::test_gemm_f16_split_is_fp32_grade) — unlike the usual "bf16x3" (three largest bf16 products, 16 bits:
 // 360 x worse), which moved the model's log-probs by 3.5e-3 and was rejected in round 2.
 //
-// Scaling.  fp16's exponent range is what this form pays with.  Activations are staged as a * S_a, weights as w * S_w
-// (powers of two: exact), the accumulator is multiplied by 1 / (S_a S_w) in the epilogue:
-//   * overflow: an operand with |a| >= 65504 / S_a (or +-Inf) saturates the high plane and overflows the low one: every output
+// Scaling.  fp16's exponent range is what this form pays with.  Weights are staged as w * S_w (a power of two: exact) and the
+// accumulator is multiplied by 1 / S_w in the epilogue; activations are staged as they are (S_a = 1):
+//   * overflow: an operand with |a| >= 65504 (or +-Inf) saturates the high plane and overflows the low one: every output
 //     of its row is Inf / NaN — a loud failure, as the bf16 form has for Inf.  S_w is chosen per weight matrix at load time
 //     from its largest magnitude (kernels.h best_w_scale: max |w| S_w <= 32768, never overflows); S_a = 1: |a| < 65504.
 //     Inputs beyond that belong on the bf16 form (PFHIP_GEMM_X3=0), whose range is fp32's;
@@ -28,6 +28,20 @@
 // operands split while staged, LDS double-buffered, one hand-made barrier per K-step; LayerNorm folded in through the row
 // statistics hand-off) with two planes instead of three: per K-step and wave 12 / 6 / 3 MFMAs, 8 / 6 / 4 fragment reads.
 #include "kernels.h"
+
+// Timing-only ablations of the K-step (tools/x3_ablate.sh builds one library per value; results are WRONG for any value but 0):
+//   1 no s_barrier   2 no split / LDS writes   3 no fragment reads   4 no global loads   5 MFMAs only (2 + 3 + 4, barrier kept)
+#ifndef PFHIP_X3_ABLATE
+#define PFHIP_X3_ABLATE 0
+#endif
+#if PFHIP_X3_ABLATE == 1
+#define PFHIP_X3_BARRIER "s_waitcnt lgkmcnt(0)"
+#else
+#define PFHIP_X3_BARRIER "s_waitcnt lgkmcnt(0)\n\ts_barrier"
+#endif
+#define PFHIP_X3_DO_SPLIT (PFHIP_X3_ABLATE != 2 && PFHIP_X3_ABLATE != 5)
+#define PFHIP_X3_DO_READ (PFHIP_X3_ABLATE != 3 && PFHIP_X3_ABLATE != 5)
+#define PFHIP_X3_DO_LOAD (PFHIP_X3_ABLATE != 4 && PFHIP_X3_ABLATE != 5)
 
 #include <algorithm>
 #include <atomic>
@@ -45,7 +59,8 @@ constexpr int kRowB = 48;                                   // bytes per operand
 constexpr int kPlaneA = kBM * kRowB, kPlaneW = kBN * kRowB; // bytes per plane
 constexpr int kStageB = 2 * (kPlaneA + kPlaneW);            // 36,864 B
 constexpr int kCs = kBN + 4;                                // padded C-tile row stride (floats)
-constexpr int kLdsBytes = 2 * kStageB;                      // 73,728 B
+constexpr int kRing = 3;                                    // LDS stages: the one being read, the next one (read ahead), the one being written
+constexpr int kLdsBytes = kRing * kStageB;                  // 110,592 B
 static_assert(128 * kCs * 4 <= kLdsBytes, "half C tile must fit the operand buffers");
 
 // x - (float)h for the low / high half of a packed fp16 pair, ONE instruction each (v_fma_mix_f32 reads an fp16 source in
@@ -74,6 +89,23 @@ __device__ __forceinline__ void split2(const float4& v, float scale, unsigned ch
   const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, half2v));
   const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, half2v));
   *reinterpret_cast<uint2*>(base + plane_bytes) = make_uint2(l01, l23);
+}
+
+// The same split in two pieces that can be placed between MFMAs by hand: HI writes the high plane of a float4 and keeps the four
+// residuals (and, scaled, the products), LO rounds and writes the low plane.
+struct SplitTmp { float r0, r1, r2, r3; };
+template <bool SC>
+__device__ __forceinline__ void split_hi(const float4& v, float scale, unsigned char* dst, SplitTmp& t) {
+  const float x0 = SC ? v.x * scale : v.x, x1 = SC ? v.y * scale : v.y, x2 = SC ? v.z * scale : v.z, x3 = SC ? v.w * scale : v.w;
+  const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x2, x3));
+  *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+  t.r0 = sub_lo(x0, h01); t.r1 = sub_hi(x1, h01); t.r2 = sub_lo(x2, h23); t.r3 = sub_hi(x3, h23);
+}
+__device__ __forceinline__ void split_lo(unsigned char* dst, const SplitTmp& t) {
+  const float2v r01 = {t.r0, t.r1}, r23 = {t.r2, t.r3};
+  *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r01, half2v)),
+                                              __builtin_bit_cast(unsigned, __builtin_convertvector(r23, half2v)));
 }
 
 // XCD-aware, column-group-major tile order (same scheme as gemm.hip's tile_of_block)
@@ -135,7 +167,7 @@ template <bool SC>
 __global__ __launch_bounds__(512, 1) void gemm_f32_f16x3_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
-    int n_tiles, int gw, int relu, float* __restrict__ stats_out, float sa, float sw) {
+    int n_tiles, int gw, int relu, float* __restrict__ stats_out, float sw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -163,8 +195,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_f16x3_kernel(
   RA1 = *reinterpret_cast<const float4*>(Ag1 + (k0));          \
   RW = *reinterpret_cast<const float4*>(Wg + (k0));
 #define PFHIP_SPLIT_STORE(RA0, RA1, RW, stage)                                \
-  split2<SC>(RA0, sa, lds + (stage) * kStageB + a_st, kPlaneA);                   \
-  split2<SC>(RA1, sa, lds + (stage) * kStageB + a_st + 128 * kRowB, kPlaneA);     \
+  split2<false>(RA0, 1.0f, lds + (stage) * kStageB + a_st, kPlaneA);                   \
+  split2<false>(RA1, 1.0f, lds + (stage) * kStageB + a_st + 128 * kRowB, kPlaneA);     \
   split2<SC>(RW, sw, lds + (stage) * kStageB + w_st, kPlaneW);
 
   f32x16 acc00, acc01, acc10, acc11;
@@ -186,47 +218,85 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_f16x3_kernel(
   acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa][1], FB[pb][0], acc10, 0, 0, 0);      \
   acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa][1], FB[pb][1], acc11, 0, 0, 0);
 #define PFHIP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-  // The barrier is `s_waitcnt lgkmcnt(0); s_barrier` by hand: __syncthreads() also waits for vmcnt(0), i.e. for the global
-  // loads issued a few instructions earlier — a full memory latency per K-step (measured: 1.16 us per step with it).
-  // One K-step, one barrier.  Region 1: the 8 cross-term MFMAs of this step (a1 w2, a2 w1), between them the split of the next
-  // step's operands (48 VALU ops), its 6 LDS writes and the 3 global loads of the step after.  Barrier.  Region 2: the 4
-  // a1 w1 MFMAs, between them the 8 fragment reads of the next step (into the other fragment set).  Masks: 0x8 MFMA,
-  // 0x2 VALU, 0x200 DS write, 0x100 DS read, 0x20 VMEM read.
-#define PFHIP_STEP(FA, FB, GA, GB, RA0, RA1, RW, nxt, knext)                                  \
-  PFHIP_SPLIT_STORE(RA0, RA1, RW, nxt)                                                        \
-  PFHIP_LOAD_RAW(RA0, RA1, RW, knext)                                                         \
-  PFHIP_X6(FA, FB, 0, 1) PFHIP_X6(FA, FB, 1, 0)                                               \
-  _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                             \
-    PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1);                                \
-  }                                                                                           \
-  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 2); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x20, 1);               \
-  __builtin_amdgcn_sched_barrier(0);                                                          \
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
-  __builtin_amdgcn_sched_barrier(0);                                                          \
-  PFHIP_FRAGS(GA, GB, nxt)                                                                    \
-  PFHIP_X6(FA, FB, 0, 0)                                                                      \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
-    PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 2);                                                   \
-  }                                                                                           \
-  __builtin_amdgcn_sched_barrier(0);
+  // One K-step, one barrier (`s_waitcnt lgkmcnt(0); s_barrier` by hand: __syncthreads() would also wait for vmcnt(0), i.e. for the
+  // global loads issued a few instructions earlier).  The LDS stages form a RING OF THREE: step k multiplies the fragments it
+  // already holds (stage k), reads the fragments of stage k + 1 — written during step k - 1, visible since the barrier that
+  // ended it — and writes the split of K-step k + 2 into stage k + 2 (last read during step k - 2).  So neither the fragment reads
+  // nor the split's writes sit between a barrier and the MFMAs that need them: each has the whole step's 12 MFMAs as cover.
+  // (With two stages the eight reads of all eight waves — 64 KB — landed in a burst right behind the barrier with four MFMAs
+  // to hide them.)
+  // The step is placed BY HAND, every statement pinned with a scheduling barrier: left to the compiler — sched_group_barrier
+  // patterns included — the 30-odd vector instructions of the split all ran before the first MFMA, in both waves of a SIMD at
+  // once (they meet at the barrier every step).  Between two MFMAs sit at most a pair of fragment reads or one piece of the split.
+  // Timing-only builds (PFHIP_X3_ABLATE, K = 2048, 256 x 128 tile): the real kernel 110 us; without the step barrier 107; without
+  // split + LDS writes 64; without fragment reads 83; without global loads 84; MFMAs alone 60 (562 TF: the rate the chip holds
+  // under fp16 MFMA loops) — the vector and LDS work of a step still does not hide behind its MFMAs.  Measured and dropped: a
+  // two-phase step with waves 4-7 one phase behind waves 0-3 (one group in its MFMA phase while the other stages: 134 us), a
+  // staging map whose LDS writes are bank-conflict-free (no change).
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_M(acc, A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0); PFHIP_SB;
+#define PFHIP_RA(GA, rst, p, i) if (PFHIP_X3_DO_READ) GA[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (rst) * kStageB + (p) * kPlaneA + a_fr + (i) * 32 * kRowB));
+#define PFHIP_RB(GB, rst, p, i) if (PFHIP_X3_DO_READ) GB[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (rst) * kStageB + (p) * kPlaneW + w_fr + (i) * 32 * kRowB));
+#define PFHIP_STEP(FA, FB, GA, GB, RA0, RA1, RW, wst, rst, knext)                                                              \
+  {                                                                                                                            \
+    SplitTmp t_;                                                                                                               \
+    unsigned char* const wa_ = lds + (wst) * kStageB + a_st;                                                                   \
+    unsigned char* const ww_ = lds + (wst) * kStageB + w_st;                                                                   \
+    PFHIP_M(acc00, FA[0][0], FB[1][0]) PFHIP_RA(GA, rst, 0, 0) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                               \
+    PFHIP_M(acc01, FA[0][0], FB[1][1]) if (PFHIP_X3_DO_SPLIT) split_hi<false>(RA0, 1.0f, wa_, t_); PFHIP_SB;                   \
+    PFHIP_M(acc10, FA[0][1], FB[1][0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                               \
+    PFHIP_M(acc11, FA[0][1], FB[1][1]) if (PFHIP_X3_DO_SPLIT) split_lo(wa_ + kPlaneA, t_); if (PFHIP_X3_DO_LOAD) RA0 = *reinterpret_cast<const float4*>(Ag0 + (knext)); PFHIP_SB; \
+    PFHIP_M(acc00, FA[1][0], FB[0][0]) PFHIP_RA(GA, rst, 0, 1) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                               \
+    PFHIP_M(acc01, FA[1][0], FB[0][1]) if (PFHIP_X3_DO_SPLIT) split_hi<false>(RA1, 1.0f, wa_ + 128 * kRowB, t_); PFHIP_SB;     \
+    PFHIP_M(acc10, FA[1][1], FB[0][0]) PFHIP_RA(GA, rst, 1, 1) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                               \
+    PFHIP_M(acc11, FA[1][1], FB[0][1]) if (PFHIP_X3_DO_SPLIT) split_lo(wa_ + 128 * kRowB + kPlaneA, t_); if (PFHIP_X3_DO_LOAD) RA1 = *reinterpret_cast<const float4*>(Ag1 + (knext)); PFHIP_SB; \
+    PFHIP_M(acc00, FA[0][0], FB[0][0]) if (PFHIP_X3_DO_SPLIT) split_hi<SC>(RW, sw, ww_, t_); PFHIP_SB;                         \
+    PFHIP_M(acc01, FA[0][0], FB[0][1]) if (PFHIP_X3_DO_SPLIT) split_lo(ww_ + kPlaneW, t_); if (PFHIP_X3_DO_LOAD) RW = *reinterpret_cast<const float4*>(Wg + (knext)); PFHIP_SB; \
+    PFHIP_M(acc10, FA[0][1], FB[0][0])                                                                                         \
+    PFHIP_M(acc11, FA[0][1], FB[0][1])                                                                                         \
+    asm volatile(PFHIP_X3_BARRIER ::: "memory");                                                                               \
+    PFHIP_SB;                                                                                                                  \
+  }
 
   const int nk = K / kBK;
   auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
   PFHIP_LOAD_RAW(xa0, xa1, xw, 0)
+  PFHIP_LOAD_RAW(ya0, ya1, yw, kclamp(1))
   PFHIP_SPLIT_STORE(xa0, xa1, xw, 0)
-  PFHIP_LOAD_RAW(ya0, ya1, yw, kclamp(1))                  // K-step 1 -> y, K-step 2 -> x: step kt splits set (kt + 1) & 1
-  PFHIP_LOAD_RAW(xa0, xa1, xw, kclamp(2))
+  PFHIP_SPLIT_STORE(ya0, ya1, yw, 1)
+  PFHIP_LOAD_RAW(xa0, xa1, xw, kclamp(2))                  // K-steps 2 and 3 wait in registers: step k splits K-step k + 2
+  PFHIP_LOAD_RAW(ya0, ya1, yw, kclamp(3))
   __syncthreads();
   PFHIP_FRAGS(fa, fb, 0)
 
-  // splits / loads past the last K-step redo the last one (never used): keeps the bodies straight-line
+  // step k: fragments f / g by parity, raw set x / y by parity, writes stage (k + 2) % 3, reads stage (k + 1) % 3: a period of
+  // six steps.  Splits / loads / reads past the last K-step redo the last one (never used): keeps the bodies straight-line.
+#define PFHIP_S0(kt) { const int knext = kclamp((kt) + 4); PFHIP_STEP(fa, fb, ga, gb, xa0, xa1, xw, 2, 1, knext) }
+#define PFHIP_S1(kt) { const int knext = kclamp((kt) + 5); PFHIP_STEP(ga, gb, fa, fb, ya0, ya1, yw, 0, 2, knext) }
+#define PFHIP_S2(kt) { const int knext = kclamp((kt) + 6); PFHIP_STEP(fa, fb, ga, gb, xa0, xa1, xw, 1, 0, knext) }
+#define PFHIP_S3(kt) { const int knext = kclamp((kt) + 7); PFHIP_STEP(ga, gb, fa, fb, ya0, ya1, yw, 2, 1, knext) }
+#define PFHIP_S4(kt) { const int knext = kclamp((kt) + 8); PFHIP_STEP(fa, fb, ga, gb, xa0, xa1, xw, 0, 2, knext) }
+#define PFHIP_S5(kt) { const int knext = kclamp((kt) + 9); PFHIP_STEP(ga, gb, fa, fb, ya0, ya1, yw, 1, 0, knext) }
   int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    { const int knext = kclamp(kt + 3); PFHIP_STEP(fa, fb, ga, gb, ya0, ya1, yw, 1, knext) }
-    { const int knext = kclamp(kt + 4); PFHIP_STEP(ga, gb, fa, fb, xa0, xa1, xw, 0, knext) }
-  }
-  if (kt < nk) { const int knext = kclamp(nk); PFHIP_STEP(fa, fb, ga, gb, ya0, ya1, yw, 1, knext) }
+  for (; kt + 5 < nk; kt += 6) { PFHIP_S0(kt) PFHIP_S1(kt) PFHIP_S2(kt) PFHIP_S3(kt) PFHIP_S4(kt) PFHIP_S5(kt) }
+  if (kt < nk) PFHIP_S0(kt)
+  if (kt + 1 < nk) PFHIP_S1(kt)
+  if (kt + 2 < nk) PFHIP_S2(kt)
+  if (kt + 3 < nk) PFHIP_S3(kt)
+  if (kt + 4 < nk) PFHIP_S4(kt)
+#undef PFHIP_S0
+#undef PFHIP_S1
+#undef PFHIP_S2
+#undef PFHIP_S3
+#undef PFHIP_S4
+#undef PFHIP_S5
 #undef PFHIP_STEP
+#ifdef PFHIP_M
+#undef PFHIP_M
+#undef PFHIP_RA
+#undef PFHIP_RB
+#undef PFHIP_SB
+#endif
 #undef PFHIP_SPLIT_STORE
 #undef PFHIP_LOAD_RAW
 #undef PFHIP_SGB
@@ -247,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_f16x3_kernel(
 
   // ---- epilogue: two 128-row halves through LDS (C/D map: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)) ------------------
   float* const Cs = reinterpret_cast<float*>(lds);
-  const float inv = SC ? 1.0f / (sa * sw) : 1.0f;           // powers of two: exact
+  const float inv = SC ? 1.0f / sw : 1.0f;                  // a power of two: exact
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) {
     if (gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
@@ -311,15 +381,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_f16x3_kernel(
 constexpr int kSM = 128;
 constexpr int kSPlane = kSM * kRowB;                        // 6,144 B per plane (A and W tiles have 128 rows each)
 constexpr int kSStageB = 4 * kSPlane;                       // 24,576 B
-constexpr int kSLdsBytes = 128 * (128 + 4) * 4 + 128 * 8;      // the C tile + row statistics of the epilogue (68,608 B) > 2 stages (49,152 B)
+constexpr int kSLdsBytes = kRing * kSStageB;                // 73,728 B (>= the C tile + row statistics of the epilogue, 68,608 B)
 static_assert(kSM * kCs * 4 <= kSLdsBytes, "C tile must fit the operand buffers");
 
 template <bool LN, bool SC>
-__global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_128_kernel(
+__global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_128_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
     int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
-    const float* __restrict__ ln_colsum, float sa, float sw) {
+    const float* __restrict__ ln_colsum, float sw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -350,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_128_kernel(
   RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
   RW = *reinterpret_cast<const float4*>(Wg + (k0));
 #define PFHIP_SPLIT_STORE(RA, RW, stage)                      \
-  split2<SC>(RA, sa, lds + (stage) * kSStageB + a_st, kSPlane);   \
+  split2<false>(RA, 1.0f, lds + (stage) * kSStageB + a_st, kSPlane);   \
   split2<SC>(RW, sw, lds + (stage) * kSStageB + w_st, kSPlane);
 
   f32x16 acc0, acc1;
@@ -368,37 +438,62 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_128_kernel(
   acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa][0], FB[pb], acc0, 0, 0, 0);       \
   acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa][1], FB[pb], acc1, 0, 0, 0);
 #define PFHIP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, nxt, knext)                                        \
-  PFHIP_SPLIT_STORE(RA, RW, nxt)                                                              \
-  PFHIP_LOAD_RAW(RA, RW, knext)                                                               \
-  PFHIP_X6(FA, FB, 0, 1) PFHIP_X6(FA, FB, 1, 0)                                               \
-  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1);                                  \
-  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1);                                  \
-  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1); PFHIP_SGB(0x20, 1);              \
-  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x2, 8); PFHIP_SGB(0x200, 1); PFHIP_SGB(0x20, 1);              \
-  __builtin_amdgcn_sched_barrier(0);                                                          \
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
-  __builtin_amdgcn_sched_barrier(0);                                                          \
-  PFHIP_FRAGS(GA, GB, nxt)                                                                    \
-  PFHIP_X6(FA, FB, 0, 0)                                                                      \
-  PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 3); PFHIP_SGB(0x8, 1); PFHIP_SGB(0x100, 3);             \
-  __builtin_amdgcn_sched_barrier(0);
+  // ring of three LDS stages, one hand-placed region per K-step (see the 256 x 128 kernel)
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_M(acc, A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0); PFHIP_SB;
+#define PFHIP_RA(GA, rst, p, i) if (PFHIP_X3_DO_READ) GA[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (rst) * kSStageB + (p) * kSPlane + a_fr + (i) * 32 * kRowB));
+#define PFHIP_RB(GB, rst, p) if (PFHIP_X3_DO_READ) GB[p] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (rst) * kSStageB + (p) * kSPlane + w_fr));
+#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, wst, rst, knext)                                                                    \
+  {                                                                                                                            \
+    SplitTmp t_;                                                                                                               \
+    unsigned char* const wa_ = lds + (wst) * kSStageB + a_st;                                                                  \
+    unsigned char* const ww_ = lds + (wst) * kSStageB + w_st;                                                                  \
+    PFHIP_M(acc0, FA[0][0], FB[1]) PFHIP_RA(GA, rst, 0, 0) PFHIP_RB(GB, rst, 0) PFHIP_SB;                                      \
+    PFHIP_M(acc1, FA[0][1], FB[1]) if (PFHIP_X3_DO_SPLIT) split_hi<false>(RA, 1.0f, wa_, t_); PFHIP_SB;                        \
+    PFHIP_M(acc0, FA[1][0], FB[0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_RA(GA, rst, 0, 1) if (PFHIP_X3_DO_SPLIT) split_lo(wa_ + kSPlane, t_); if (PFHIP_X3_DO_LOAD) RA = *reinterpret_cast<const float4*>(Ag + (knext)); PFHIP_SB; \
+    PFHIP_M(acc1, FA[1][1], FB[0]) if (PFHIP_X3_DO_SPLIT) split_hi<SC>(RW, sw, ww_, t_); PFHIP_SB;                             \
+    PFHIP_M(acc0, FA[0][0], FB[0]) PFHIP_RA(GA, rst, 1, 1) PFHIP_RB(GB, rst, 1) if (PFHIP_X3_DO_SPLIT) split_lo(ww_ + kSPlane, t_); if (PFHIP_X3_DO_LOAD) RW = *reinterpret_cast<const float4*>(Wg + (knext)); PFHIP_SB; \
+    PFHIP_M(acc1, FA[0][1], FB[0])                                                                                             \
+    asm volatile(PFHIP_X3_BARRIER ::: "memory");                                                                               \
+    PFHIP_SB;                                                                                                                  \
+  }
 
   const int nk = K / kBK;
   auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
   PFHIP_LOAD_RAW(xa, xw, 0)
-  PFHIP_SPLIT_STORE(xa, xw, 0)
   PFHIP_LOAD_RAW(ya, yw, kclamp(1))
+  PFHIP_SPLIT_STORE(xa, xw, 0)
+  PFHIP_SPLIT_STORE(ya, yw, 1)
   PFHIP_LOAD_RAW(xa, xw, kclamp(2))
+  PFHIP_LOAD_RAW(ya, yw, kclamp(3))
   __syncthreads();
   PFHIP_FRAGS(fa, fb, 0)
+#define PFHIP_S0(kt) { const int knext = kclamp((kt) + 4); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 2, 1, knext) }
+#define PFHIP_S1(kt) { const int knext = kclamp((kt) + 5); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 0, 2, knext) }
+#define PFHIP_S2(kt) { const int knext = kclamp((kt) + 6); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 1, 0, knext) }
+#define PFHIP_S3(kt) { const int knext = kclamp((kt) + 7); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 2, 1, knext) }
+#define PFHIP_S4(kt) { const int knext = kclamp((kt) + 8); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 0, 2, knext) }
+#define PFHIP_S5(kt) { const int knext = kclamp((kt) + 9); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 1, 0, knext) }
   int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    { const int knext = kclamp(kt + 3); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
-    { const int knext = kclamp(kt + 4); PFHIP_STEP(ga, gb, fa, fb, xa, xw, 0, knext) }
-  }
-  if (kt < nk) { const int knext = kclamp(nk); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
+  for (; kt + 5 < nk; kt += 6) { PFHIP_S0(kt) PFHIP_S1(kt) PFHIP_S2(kt) PFHIP_S3(kt) PFHIP_S4(kt) PFHIP_S5(kt) }
+  if (kt < nk) PFHIP_S0(kt)
+  if (kt + 1 < nk) PFHIP_S1(kt)
+  if (kt + 2 < nk) PFHIP_S2(kt)
+  if (kt + 3 < nk) PFHIP_S3(kt)
+  if (kt + 4 < nk) PFHIP_S4(kt)
+#undef PFHIP_S0
+#undef PFHIP_S1
+#undef PFHIP_S2
+#undef PFHIP_S3
+#undef PFHIP_S4
+#undef PFHIP_S5
 #undef PFHIP_STEP
+#ifdef PFHIP_M
+#undef PFHIP_M
+#undef PFHIP_RA
+#undef PFHIP_RB
+#undef PFHIP_SB
+#endif
 #undef PFHIP_SPLIT_STORE
 #undef PFHIP_LOAD_RAW
 #undef PFHIP_SGB
@@ -442,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_128_kernel(
   }
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
-  const float inv = SC ? 1.0f / (sa * sw) : 1.0f;           // powers of two: exact
+  const float inv = SC ? 1.0f / sw : 1.0f;                  // a power of two: exact
 #pragma unroll
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 16 + rsub;
@@ -487,15 +582,15 @@ constexpr int kHM = 64;
 constexpr int kHPlaneA = kHM * kRowB;                       // 3,072 B
 constexpr int kHPlaneW = kBN * kRowB;                       // 6,144 B
 constexpr int kHStageB = 2 * (kHPlaneA + kHPlaneW);         // 18,432 B
-constexpr int kHLdsBytes = 2 * kHStageB;                    // 36,864 B
+constexpr int kHLdsBytes = kRing * kHStageB;                // 55,296 B
 static_assert(kHM * kCs * 4 <= kHLdsBytes, "C tile must fit the operand buffers");
 
 template <bool LN, bool SC>
-__global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
+__global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_64_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
     int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
-    const float* __restrict__ ln_colsum, float sa, float sw) {
+    const float* __restrict__ ln_colsum, float sw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -521,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
   if (stage_a) RA = *reinterpret_cast<const float4*>(Ag + (k0));             \
   RW = *reinterpret_cast<const float4*>(Wg + (k0));
 #define PFHIP_SPLIT_STORE(RA, RW, stage)                                                              \
-  if (stage_a) split2<SC>(RA, sa, lds + (stage) * kHStageB + a_st, kHPlaneA);                             \
+  if (stage_a) split2<false>(RA, 1.0f, lds + (stage) * kHStageB + a_st, kHPlaneA);                             \
   split2<SC>(RW, sw, lds + (stage) * kHStageB + w_st, kHPlaneW);
 
   f32x16 acc;
@@ -535,32 +630,52 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
     FB[p] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (stage) * kHStageB + p * kHPlaneW + w_fr)); \
   }
 #define PFHIP_X6(FA, FB, pa, pb) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa], FB[pb], acc, 0, 0, 0);
-#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, nxt, knext)                                        \
-  PFHIP_SPLIT_STORE(RA, RW, nxt)                                                              \
+  // ring of three LDS stages, one region per K-step (see the 256 x 128 kernel); the compiler orders the region
+#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, wst, rst, knext)                                   \
+  PFHIP_SPLIT_STORE(RA, RW, wst)                                                              \
   PFHIP_LOAD_RAW(RA, RW, knext)                                                               \
-  PFHIP_X6(FA, FB, 0, 1) PFHIP_X6(FA, FB, 1, 0)                                               \
+  PFHIP_FRAGS(GA, GB, rst)                                                                    \
+  PFHIP_X6(FA, FB, 0, 1) PFHIP_X6(FA, FB, 1, 0) PFHIP_X6(FA, FB, 0, 0)                        \
   __builtin_amdgcn_sched_barrier(0);                                                          \
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
-  __builtin_amdgcn_sched_barrier(0);                                                          \
-  PFHIP_FRAGS(GA, GB, nxt)                                                                    \
-  PFHIP_X6(FA, FB, 0, 0)                                                                      \
+  asm volatile(PFHIP_X3_BARRIER ::: "memory");                              \
   __builtin_amdgcn_sched_barrier(0);
 
   const int nk = K / kBK;
   auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
   PFHIP_LOAD_RAW(xa, xw, 0)
-  PFHIP_SPLIT_STORE(xa, xw, 0)
   PFHIP_LOAD_RAW(ya, yw, kclamp(1))
+  PFHIP_SPLIT_STORE(xa, xw, 0)
+  PFHIP_SPLIT_STORE(ya, yw, 1)
   PFHIP_LOAD_RAW(xa, xw, kclamp(2))
+  PFHIP_LOAD_RAW(ya, yw, kclamp(3))
   __syncthreads();
   PFHIP_FRAGS(fa, fb, 0)
+#define PFHIP_S0(kt) { const int knext = kclamp((kt) + 4); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 2, 1, knext) }
+#define PFHIP_S1(kt) { const int knext = kclamp((kt) + 5); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 0, 2, knext) }
+#define PFHIP_S2(kt) { const int knext = kclamp((kt) + 6); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 1, 0, knext) }
+#define PFHIP_S3(kt) { const int knext = kclamp((kt) + 7); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 2, 1, knext) }
+#define PFHIP_S4(kt) { const int knext = kclamp((kt) + 8); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 0, 2, knext) }
+#define PFHIP_S5(kt) { const int knext = kclamp((kt) + 9); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 1, 0, knext) }
   int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    { const int knext = kclamp(kt + 3); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
-    { const int knext = kclamp(kt + 4); PFHIP_STEP(ga, gb, fa, fb, xa, xw, 0, knext) }
-  }
-  if (kt < nk) { const int knext = kclamp(nk); PFHIP_STEP(fa, fb, ga, gb, ya, yw, 1, knext) }
+  for (; kt + 5 < nk; kt += 6) { PFHIP_S0(kt) PFHIP_S1(kt) PFHIP_S2(kt) PFHIP_S3(kt) PFHIP_S4(kt) PFHIP_S5(kt) }
+  if (kt < nk) PFHIP_S0(kt)
+  if (kt + 1 < nk) PFHIP_S1(kt)
+  if (kt + 2 < nk) PFHIP_S2(kt)
+  if (kt + 3 < nk) PFHIP_S3(kt)
+  if (kt + 4 < nk) PFHIP_S4(kt)
+#undef PFHIP_S0
+#undef PFHIP_S1
+#undef PFHIP_S2
+#undef PFHIP_S3
+#undef PFHIP_S4
+#undef PFHIP_S5
 #undef PFHIP_STEP
+#ifdef PFHIP_M
+#undef PFHIP_M
+#undef PFHIP_RA
+#undef PFHIP_RB
+#undef PFHIP_SB
+#endif
 #undef PFHIP_SPLIT_STORE
 #undef PFHIP_LOAD_RAW
 #undef PFHIP_X6
@@ -599,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
   }
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
-  const float inv = SC ? 1.0f / (sa * sw) : 1.0f;           // powers of two: exact
+  const float inv = SC ? 1.0f / sw : 1.0f;                  // a power of two: exact
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int row = pass * 16 + rsub;
@@ -652,10 +767,10 @@ void launch_with_lds(int n_tiles, int lds_bytes, hipStream_t s, Args... args) {
 
 void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
-                           const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, float sa, float sw) {
+                           const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, float sw) {
   if (M <= 0 || N <= 0) return;
   if (ln_stats) small_tile = true;              // LayerNorm-on-load lives in the 128 / 64-row kernels (its consumers have K = 512)
-  const bool sc = sa != 1.0f || sw != 1.0f;
+  const bool sc = sw != 1.0f;
   const int rl = relu ? 1 : 0;
   const float eps = 1e-12f;
   const int tiles_n = (N + kBN - 1) / kBN;
@@ -663,10 +778,10 @@ void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, flo
 #define PFHIP_X3_LAUNCH_LN(KERN, TM, LDS)                                                                                        \
   {                                                                                                                              \
     const int n_tiles = ((M + (TM) - 1) / (TM)) * tiles_n;                                                                       \
-    if (ln_stats && sc) launch_with_lds<KERN<true, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sa, sw);      \
-    else if (ln_stats) launch_with_lds<KERN<true, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sa, sw);       \
-    else if (sc) launch_with_lds<KERN<false, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sa, sw);            \
-    else launch_with_lds<KERN<false, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sa, sw);                    \
+    if (ln_stats && sc) launch_with_lds<KERN<true, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);      \
+    else if (ln_stats) launch_with_lds<KERN<true, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);       \
+    else if (sc) launch_with_lds<KERN<false, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);            \
+    else launch_with_lds<KERN<false, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);                    \
   }
   if (small_tile && half_tile) {
     PFHIP_X3_LAUNCH_LN(gemm_f32_f16x3_64_kernel, kHM, kHLdsBytes)
@@ -678,8 +793,8 @@ void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, flo
   }
 #undef PFHIP_X3_LAUNCH_LN
   const int n_tiles = ((M + kBM - 1) / kBM) * tiles_n;
-  if (sc) launch_with_lds<gemm_f32_f16x3_kernel<true>>(n_tiles, kLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, stats_out, sa, sw);
-  else launch_with_lds<gemm_f32_f16x3_kernel<false>>(n_tiles, kLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, stats_out, sa, sw);
+  if (sc) launch_with_lds<gemm_f32_f16x3_kernel<true>>(n_tiles, kLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, stats_out, sw);
+  else launch_with_lds<gemm_f32_f16x3_kernel<false>>(n_tiles, kLdsBytes, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, stats_out, sw);
 }
 
 }  // namespace pfhip

@@ -64,10 +64,10 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
                             int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile = false,
                             const float* ln_stats = nullptr, int ln_tiles = 0, float* stats_out = nullptr, bool half_tile = false,
                             const float* ln_colsum = nullptr);
-// the same tilings with TWO fp16 planes and THREE products per block (gemm_x3.hip); sa / sw: power-of-two operand scales
+// the same tilings with TWO fp16 planes and THREE products per block (gemm_x3.hip); sw: the power-of-two weight scale
 void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
-                           const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, float sa, float sw);
+                           const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, float sw);
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).

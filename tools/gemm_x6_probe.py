@@ -12,6 +12,8 @@ ops = importlib.import_module("asr_2pass_amd.ops")
 torch.manual_seed(0)
 kinds = [int(x) for x in os.environ.get("KINDS", "1,4").split(",")]
 shapes = [(16000, 1536, 512), (16000, 512, 512), (16000, 2048, 512), (16000, 512, 2048), (3840, 8404, 512), (3840, 1024, 512), (1000, 512, 512)]
+if os.environ.get("SHAPES") == "enc4":
+    shapes = [(16000, 1536, 512), (16000, 512, 512), (16000, 2048, 512), (16000, 512, 2048)]
 if os.environ.get("SHAPES") == "dec":
     shapes = [(M, N, K) for M in (2048, 4000, 7015, 12000) for (N, K) in ((512, 512), (1024, 512), (2048, 512), (512, 2048), (1536, 512))] + [(7015, 8404, 512)]
 for (M, N, K) in shapes:

@@ -572,21 +572,23 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_128_kernel(
 }
 
 
-// ---- 64 x 128 sibling for grids between a quarter and three quarters of the chip's 512 workgroup slots — the decoder's
-// N = 512 launches over ML ~ 7000 token rows are 220 tiles of 128 x 128: one workgroup on 220 CUs, nothing to overlap its
-// prologue and epilogue with, 77 TF.  Half-height tiles double the count (two workgroups on most CUs).  8 waves as 2 x 4, each
-// ONE 32 x 32 MFMA tile; A is staged by waves 0-3 (64 rows), W by all (128 rows); LDS 2 x 27,648 B.  Per K-step and wave:
-// 6 MFMAs, 22-44 VALU ops of splitting, 3-6 LDS writes, 1-2 global loads, 6 fragment reads — more overhead per flop than the
-// 128 x 128 tile, which stays the choice wherever its grid fills the slots.
-constexpr int kHM = 64;
-constexpr int kHPlaneA = kHM * kRowB;                       // 3,072 B
-constexpr int kHPlaneW = kBN * kRowB;                       // 6,144 B
-constexpr int kHStageB = 2 * (kHPlaneA + kHPlaneW);         // 18,432 B
-constexpr int kHLdsBytes = kRing * kHStageB;                // 55,296 B
-static_assert(kHM * kCs * 4 <= kHLdsBytes, "C tile must fit the operand buffers");
+// ---- 64 x 128 sibling for grids that would leave most of a round of 128 x 128 tiles empty (at most 256 of these tiles: rounds of
+// streaming connections — 128 x 20 rows = 160 tiles at N = 512 —, offline batches of a few utterances): ONE workgroup per CU, so
+// nothing hides a step's fixed costs (the barrier, the LDS write -> read turn-around, the issue of the split) but the step's own
+// MFMAs, and a wave owns a single 32 x 32 tile: three MFMAs per 16-deep step.  This kernel therefore takes K-steps of 32 — two
+// MFMA depths, six MFMAs per wave between barriers, 128-byte row pieces per global load (full cache lines; the 16-deep kernels
+// load 64-byte pieces) — in a ring of three stages of 30,720 B.  8 waves as 2 x 4; every thread stages one float4 of A (64 rows)
+// and two of W (128 rows).
+constexpr int kHM = 64, kHK = 32;
+constexpr int kHRowB = 80;                                  // bytes per operand row: 32 fp16 + 16 pad (conflict-free ds_read_b128)
+constexpr int kHPlaneA = kHM * kHRowB;                      // 5,120 B
+constexpr int kHPlaneW = kBN * kHRowB;                      // 10,240 B
+constexpr int kHStageB = 2 * (kHPlaneA + kHPlaneW);         // 30,720 B
+constexpr int kHLdsBytes = kRing * kHStageB;                // 92,160 B
+static_assert(kHM * kCs * 4 + kHM * 8 <= kHLdsBytes, "C tile + row statistics must fit the operand buffers");
 
 template <bool LN, bool SC>
-__global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_64_kernel(
+__global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
     int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
@@ -600,62 +602,77 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_64_kernel(
   const int wr = wave >> 2, wc = wave & 3;
   const int r = lane & 31, h = lane >> 5;
 
-  const int srow = tid >> 2, sq = tid & 3;
-  const bool stage_a = srow < kHM;                           // waves 0-3 (wave-uniform)
-  const float* Ag = A + (size_t)min(m0 + (stage_a ? srow : 0), M - 1) * lda + 4 * sq;
-  const float* Wg = W + (size_t)min(n0 + srow, N - 1) * ldw + 4 * sq;
-  const int a_st = srow * kRowB + 8 * sq;
-  const int w_st = 2 * kHPlaneA + srow * kRowB + 8 * sq;
-  const int a_fr = (wr * 32 + r) * kRowB + 16 * h;
-  const int w_fr = 2 * kHPlaneA + (wc * 32 + r) * kRowB + 16 * h;
+  // staging map: thread t holds 4 consecutive k (one of the eight 16-B pieces of a row's 128-B K-step) of A row t/8 and of W
+  // rows t/8 and t/8 + 64: a wave's load instruction covers 8 rows x 128 contiguous bytes
+  const int srow = tid >> 3, sq = tid & 7;
+  const float* Ag = A + (size_t)min(m0 + srow, M - 1) * lda + 4 * sq;
+  const float* Wg0 = W + (size_t)min(n0 + srow, N - 1) * ldw + 4 * sq;
+  const float* Wg1 = W + (size_t)min(n0 + srow + 64, N - 1) * ldw + 4 * sq;
+  const int a_st = srow * kHRowB + 8 * sq;
+  const int w_st = 2 * kHPlaneA + srow * kHRowB + 8 * sq;
+  const int a_fr = (wr * 32 + r) * kHRowB + 16 * h;               // + 32 per 16-deep half of the step
+  const int w_fr = 2 * kHPlaneA + (wc * 32 + r) * kHRowB + 16 * h;
 
   float2 ln_mr = make_float2(0.f, 1.f);
   if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
-  float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xw, ya = xa, yw;
-#define PFHIP_LOAD_RAW(RA, RW, k0)                                           \
-  if (stage_a) RA = *reinterpret_cast<const float4*>(Ag + (k0));             \
-  RW = *reinterpret_cast<const float4*>(Wg + (k0));
-#define PFHIP_SPLIT_STORE(RA, RW, stage)                                                              \
-  if (stage_a) split2<false>(RA, 1.0f, lds + (stage) * kHStageB + a_st, kHPlaneA);                             \
-  split2<SC>(RW, sw, lds + (stage) * kHStageB + w_st, kHPlaneW);
+  float4 xa, xw0, xw1, ya, yw0, yw1;
+#define PFHIP_LOAD_RAW(RA, RW0, RW1, k0)                      \
+  RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
+  RW0 = *reinterpret_cast<const float4*>(Wg0 + (k0));         \
+  RW1 = *reinterpret_cast<const float4*>(Wg1 + (k0));
+#define PFHIP_SPLIT_STORE(RA, RW0, RW1, stage)                                                    \
+  split2<false>(RA, 1.0f, lds + (stage) * kHStageB + a_st, kHPlaneA);                             \
+  split2<SC>(RW0, sw, lds + (stage) * kHStageB + w_st, kHPlaneW);                                 \
+  split2<SC>(RW1, sw, lds + (stage) * kHStageB + w_st + 64 * kHRowB, kHPlaneW);
 
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-  half8 fa[2], fb[2], ga[2], gb[2];
+  // operand fragments [plane][16-deep half of the step]: even K-steps in f*, odd in g*
+  half8 fa[2][2], fb[2][2], ga[2][2], gb[2][2];
+#define PFHIP_RA(GA, rst, p, ks) if (PFHIP_X3_DO_READ) GA[p][ks] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (rst) * kHStageB + (p) * kHPlaneA + a_fr + 32 * (ks)));
+#define PFHIP_RB(GB, rst, p, ks) if (PFHIP_X3_DO_READ) GB[p][ks] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (rst) * kHStageB + (p) * kHPlaneW + w_fr + 32 * (ks)));
 #define PFHIP_FRAGS(FA, FB, stage)                                                                                  \
   _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                   \
-    FA[p] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (stage) * kHStageB + p * kHPlaneA + a_fr)); \
-    FB[p] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (stage) * kHStageB + p * kHPlaneW + w_fr)); \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { PFHIP_RA(FA, stage, p, ks) PFHIP_RB(FB, stage, p, ks) }       \
   }
-#define PFHIP_X6(FA, FB, pa, pb) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa], FB[pb], acc, 0, 0, 0);
-  // ring of three LDS stages, one region per K-step (see the 256 x 128 kernel); the compiler orders the region
-#define PFHIP_STEP(FA, FB, GA, GB, RA, RW, wst, rst, knext)                                   \
-  PFHIP_SPLIT_STORE(RA, RW, wst)                                                              \
-  PFHIP_LOAD_RAW(RA, RW, knext)                                                               \
-  PFHIP_FRAGS(GA, GB, rst)                                                                    \
-  PFHIP_X6(FA, FB, 0, 1) PFHIP_X6(FA, FB, 1, 0) PFHIP_X6(FA, FB, 0, 0)                        \
-  __builtin_amdgcn_sched_barrier(0);                                                          \
-  asm volatile(PFHIP_X3_BARRIER ::: "memory");                              \
-  __builtin_amdgcn_sched_barrier(0);
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_M(A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0); PFHIP_SB;
+  // ring of three LDS stages, one hand-placed region per K-step of 32 (see the 256 x 128 kernel): per 16-deep half the products
+  // a_hi w_lo, a_lo w_hi, a_hi w_hi, in that order
+#define PFHIP_STEP(FA, FB, GA, GB, RA, RW0, RW1, wst, rst, knext)                                                              \
+  {                                                                                                                            \
+    SplitTmp t_;                                                                                                               \
+    unsigned char* const wa_ = lds + (wst) * kHStageB + a_st;                                                                  \
+    unsigned char* const ww_ = lds + (wst) * kHStageB + w_st;                                                                  \
+    PFHIP_M(FA[0][0], FB[1][0]) PFHIP_RA(GA, rst, 0, 0) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                      \
+    PFHIP_M(FA[1][0], FB[0][0]) if (PFHIP_X3_DO_SPLIT) split_hi<false>(RA, 1.0f, wa_, t_); PFHIP_SB;                           \
+    PFHIP_M(FA[0][0], FB[0][0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_RB(GB, rst, 1, 0) if (PFHIP_X3_DO_SPLIT) split_lo(wa_ + kHPlaneA, t_); if (PFHIP_X3_DO_LOAD) RA = *reinterpret_cast<const float4*>(Ag + (knext)); PFHIP_SB; \
+    PFHIP_M(FA[0][1], FB[1][1]) if (PFHIP_X3_DO_SPLIT) split_hi<SC>(RW0, sw, ww_, t_); PFHIP_SB;                               \
+    PFHIP_M(FA[1][1], FB[0][1]) PFHIP_RA(GA, rst, 0, 1) PFHIP_RB(GB, rst, 0, 1) if (PFHIP_X3_DO_SPLIT) split_lo(ww_ + kHPlaneW, t_); if (PFHIP_X3_DO_LOAD) RW0 = *reinterpret_cast<const float4*>(Wg0 + (knext)); PFHIP_SB; \
+    PFHIP_M(FA[0][1], FB[0][1]) if (PFHIP_X3_DO_SPLIT) { split_hi<SC>(RW1, sw, ww_ + 64 * kHRowB, t_); split_lo(ww_ + 64 * kHRowB + kHPlaneW, t_); } \
+    if (PFHIP_X3_DO_LOAD) RW1 = *reinterpret_cast<const float4*>(Wg1 + (knext)); PFHIP_RA(GA, rst, 1, 1) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB; \
+    asm volatile(PFHIP_X3_BARRIER ::: "memory");                                                                               \
+    PFHIP_SB;                                                                                                                  \
+  }
 
-  const int nk = K / kBK;
-  auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kBK; };
-  PFHIP_LOAD_RAW(xa, xw, 0)
-  PFHIP_LOAD_RAW(ya, yw, kclamp(1))
-  PFHIP_SPLIT_STORE(xa, xw, 0)
-  PFHIP_SPLIT_STORE(ya, yw, 1)
-  PFHIP_LOAD_RAW(xa, xw, kclamp(2))
-  PFHIP_LOAD_RAW(ya, yw, kclamp(3))
+  const int nk = K / kHK;
+  auto kclamp = [&](int t) { return (t < nk ? t : nk - 1) * kHK; };
+  PFHIP_LOAD_RAW(xa, xw0, xw1, 0)
+  PFHIP_LOAD_RAW(ya, yw0, yw1, kclamp(1))
+  PFHIP_SPLIT_STORE(xa, xw0, xw1, 0)
+  PFHIP_SPLIT_STORE(ya, yw0, yw1, 1)
+  PFHIP_LOAD_RAW(xa, xw0, xw1, kclamp(2))
+  PFHIP_LOAD_RAW(ya, yw0, yw1, kclamp(3))
   __syncthreads();
   PFHIP_FRAGS(fa, fb, 0)
-#define PFHIP_S0(kt) { const int knext = kclamp((kt) + 4); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 2, 1, knext) }
-#define PFHIP_S1(kt) { const int knext = kclamp((kt) + 5); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 0, 2, knext) }
-#define PFHIP_S2(kt) { const int knext = kclamp((kt) + 6); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 1, 0, knext) }
-#define PFHIP_S3(kt) { const int knext = kclamp((kt) + 7); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 2, 1, knext) }
-#define PFHIP_S4(kt) { const int knext = kclamp((kt) + 8); PFHIP_STEP(fa, fb, ga, gb, xa, xw, 0, 2, knext) }
-#define PFHIP_S5(kt) { const int knext = kclamp((kt) + 9); PFHIP_STEP(ga, gb, fa, fb, ya, yw, 1, 0, knext) }
+#define PFHIP_S0(kt) { const int knext = kclamp((kt) + 4); PFHIP_STEP(fa, fb, ga, gb, xa, xw0, xw1, 2, 1, knext) }
+#define PFHIP_S1(kt) { const int knext = kclamp((kt) + 5); PFHIP_STEP(ga, gb, fa, fb, ya, yw0, yw1, 0, 2, knext) }
+#define PFHIP_S2(kt) { const int knext = kclamp((kt) + 6); PFHIP_STEP(fa, fb, ga, gb, xa, xw0, xw1, 1, 0, knext) }
+#define PFHIP_S3(kt) { const int knext = kclamp((kt) + 7); PFHIP_STEP(ga, gb, fa, fb, ya, yw0, yw1, 2, 1, knext) }
+#define PFHIP_S4(kt) { const int knext = kclamp((kt) + 8); PFHIP_STEP(fa, fb, ga, gb, xa, xw0, xw1, 0, 2, knext) }
+#define PFHIP_S5(kt) { const int knext = kclamp((kt) + 9); PFHIP_STEP(ga, gb, fa, fb, ya, yw0, yw1, 1, 0, knext) }
   int kt = 0;
   for (; kt + 5 < nk; kt += 6) { PFHIP_S0(kt) PFHIP_S1(kt) PFHIP_S2(kt) PFHIP_S3(kt) PFHIP_S4(kt) PFHIP_S5(kt) }
   if (kt < nk) PFHIP_S0(kt)
@@ -670,15 +687,12 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_64_kernel(
 #undef PFHIP_S4
 #undef PFHIP_S5
 #undef PFHIP_STEP
-#ifdef PFHIP_M
 #undef PFHIP_M
 #undef PFHIP_RA
 #undef PFHIP_RB
 #undef PFHIP_SB
-#endif
 #undef PFHIP_SPLIT_STORE
 #undef PFHIP_LOAD_RAW
-#undef PFHIP_X6
 #undef PFHIP_FRAGS
   // residual rows of the whole tile requested before the accumulators go through LDS: one memory latency for the epilogue
   // instead of one per pass

@@ -11,9 +11,9 @@
 // (workgroup i is dispatched to XCD i % 8: direction d = blocks with blockIdx % 8 == d): its 32 blocks exchange h
 // through that XCD's own L2, which is coherent for them — plain stores (L1 is write-through) + `s_waitcnt vmcnt(0)`,
 // a counter in the same L2, and `sc1` loads that bypass the reader's L1.  No cache-wide operation in the loop.
-// A block owns 16 hidden units x 4 gates = 64 rows of W_hh, held in VGPRs as MFMA B fragments for the whole sequence;
-// per step it reads the previous h[B,512] (64 KB, L2), runs 2 x 4 x 16 v_mfma_f32_16x16x4_f32 per wave (the 8 waves
-// split K), reduces through LDS, updates its 16 x B cells (c stays in registers) and publishes 16 x B new h values.
+// A block owns 16 hidden units x 4 gates = 64 rows of W_hh, held in VGPRs as MFMA B fragments (fp16 planes) for the whole sequence;
+// per step it reads the previous h[B,512] (64 KB, L2), runs 2 x 4 x 6 v_mfma_f32_16x16x32_f16 per wave (two fp16 planes per
+// operand, three products; the 8 waves split K), reduces through LDS, updates its 16 x B cells (c stays in registers) and publishes 16 x B new h values.
 // All utterances of a launch (<= 32) advance together; each walks its own frames (packed layout, no padding frames: a
 // padded batch would feed pad frames into the backward direction).  Placement is verified on the device (XCC_ID).
 #include "kernels.h"
@@ -37,6 +37,91 @@ constexpr int kKL = kH / kWaves / 4;  // k per lane (4 lane groups per wave)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- the recurrent product on the FP16 matrix cores ----------------------------------------------------------------------------
+// h[B,512] x W_hh^T on `v_mfma_f32_16x16x4_f32` is 2.1 MFLOP per block and step at the fp32 matrix rate (= the vector rate):
+// 3.4 us of a 7.7-us step.  Both operands are staged as two fp16 planes instead (hi = rtz(x), lo = rn(x - hi): 22-23 significant
+// bits, the scheme of gemm_x3.hip, whose header states the precision argument) and multiplied with three
+// `v_mfma_f32_16x16x32_f16` per 32 k (hi lo + lo hi + hi hi, fp32 accumulation): 48 MFMAs of 16 cycles per wave and step instead
+// of 128 of 32.  |h| < 1 always; W_hh is staged times 2^10 (|w| < 32) so that its low plane stays out of fp16's subnormal range,
+// and the accumulators are scaled back before the reduction.
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using float2v = __attribute__((ext_vector_type(2))) float;
+constexpr float kWScale = 1024.0f, kWScaleInv = 1.0f / 1024.0f;
+
+__device__ __forceinline__ float sub_lo(float x, unsigned h) {      // x - (float)low half of h, one instruction, exact
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float sub_hi(float x, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+// eight consecutive-k values of one lane -> the hi / lo operand fragments of a 16x16x32 MFMA
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+  uint4 a, b;
+  unsigned* ap = &a.x;
+  unsigned* bp = &b.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ap[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]));
+    const float2v r = {sub_lo(v[2 * i], ap[i]), sub_hi(v[2 * i + 1], ap[i])};
+    bp[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
+  }
+  hi = __builtin_bit_cast(half8, a);
+  lo = __builtin_bit_cast(half8, b);
+}
+// W_hh rows of this lane: [gate][16 consecutive k] fp32 -> fragments [gate][k half]
+struct WFrags { half8 hi[4][2], lo[4][2]; };
+__device__ __forceinline__ void load_w_frags(const float* __restrict__ whh, int dir, int unit0, int n, int kbase, WFrags& w) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* wrow = whh + ((size_t)dir * 4 * 512 + (size_t)g * 512 + unit0 + n) * 512 + kbase;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float4 v0 = *reinterpret_cast<const float4*>(wrow + 8 * m), v1 = *reinterpret_cast<const float4*>(wrow + 8 * m + 4);
+      const float v[8] = {v0.x * kWScale, v0.y * kWScale, v0.z * kWScale, v0.w * kWScale,
+                          v1.x * kWScale, v1.y * kWScale, v1.z * kWScale, v1.w * kWScale};
+      split8(v, w.hi[g][m], w.lo[g][m]);
+    }
+  }
+}
+// one utterance tile: 16 consecutive k of h per lane (four f32x4) x the W fragments -> four gate accumulators (scaled by kWScale)
+using f32x4_ = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void recur_mfma(const f32x4_ (&h)[4], const WFrags& w, f32x4_ (&acc)[4]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float v[8] = {h[2 * m][0], h[2 * m][1], h[2 * m][2], h[2 * m][3], h[2 * m + 1][0], h[2 * m + 1][1], h[2 * m + 1][2], h[2 * m + 1][3]};
+    half8 ahi, alo;
+    split8(v, ahi, alo);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w.lo[g][m], acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, w.hi[g][m], acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w.hi[g][m], acc[g], 0, 0, 0);
+    }
+  }
+}
+
+// both utterance tiles of a step at once: ONE L2 round trip instead of two on the step's critical path
+__device__ __forceinline__ void load32_l2(const float* p, const float* q, f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f,
+                                          f32x4& g, f32x4& h) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n"
+      "global_load_dwordx4 %1, %8, off offset:16 sc1\n"
+      "global_load_dwordx4 %2, %8, off offset:32 sc1\n"
+      "global_load_dwordx4 %3, %8, off offset:48 sc1\n"
+      "global_load_dwordx4 %4, %9, off sc1\n"
+      "global_load_dwordx4 %5, %9, off offset:16 sc1\n"
+      "global_load_dwordx4 %6, %9, off offset:32 sc1\n"
+      "global_load_dwordx4 %7, %9, off offset:48 sc1\n"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h)
+      : "v"(p), "v"(q)
+      : "memory");
+}
 // 64 contiguous bytes per lane, loaded past this CU's L1 (`sc1`: the data was written by other CUs of the same XCD since
 // the last step).  The loads AND their wait are one asm statement: the compiler does not count asm loads, so outside
 // of it the destination registers could be copied before the data has landed.
@@ -72,17 +157,9 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
   const int kbase = 4 * kKL * wave + kKL * kq;            // this lane's kKL consecutive k (same mapping for A and B)
   const unsigned my_xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;
   if (blk == 0 && tid == 0) bar[4 + dir] = my_xcc + 1u;        // 0 = never written
-  // B fragments: n-tile g = gate g, column n = unit n of this block
-  float wreg[4][kKL];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float* wrow = whh + ((size_t)dir * 4 * kH + (size_t)g * kH + unit0 + n) * kH + kbase;
-#pragma unroll
-    for (int s4 = 0; s4 < kKL / 4; ++s4) {
-      const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * s4);
-      wreg[g][4 * s4] = v.x; wreg[g][4 * s4 + 1] = v.y; wreg[g][4 * s4 + 2] = v.z; wreg[g][4 * s4 + 3] = v.w;
-    }
-  }
+  // B fragments (two fp16 planes, resident for the whole sequence): n-tile g = gate g, column n = unit n of this block
+  WFrags wf;
+  load_w_frags(whh, dir, unit0, n, kbase, wf);
   // cell owner: thread tid -> utterance tid >> 4, unit tid & 15 (32 x 16 = 512 = one cell per thread)
   const int cb = tid >> 4, cu = tid & 15;
   const bool own = cb < B;
@@ -111,10 +188,10 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
     f32x4 ha[kKL / 4], hb[kKL / 4];
     {
       const float* a0 = hprev + (size_t)n * kH + kbase;
-      load16_l2(a0, ha[0], ha[1], ha[2], ha[3]);
       if (two_tiles) {
-        load16_l2(a0 + 16 * kH, hb[0], hb[1], hb[2], hb[3]);
+        load32_l2(a0, a0 + 16 * kH, ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]);
       } else {
+        load16_l2(a0, ha[0], ha[1], ha[2], ha[3]);
 #pragma unroll
         for (int s4 = 0; s4 < kKL / 4; ++s4) hb[s4] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -122,25 +199,15 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
     f32x4 acc[2][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int s4 = 0; s4 < kKL / 4; ++s4) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s4][e], wreg[g][4 * s4 + e], acc[0][g], 0, 0, 0);
-        if (two_tiles) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[s4][e], wreg[g][4 * s4 + e], acc[1][g], 0, 0, 0);
-        }
-      }
-    }
+    recur_mfma(ha, wf, acc[0]);
+    if (two_tiles) recur_mfma(hb, wf, acc[1]);
     // D[i][j]: j = lane & 15 (unit), i = 4 * (lane >> 4) + r (utterance within the tile); column g*16 + unit
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        red[wave][4 * kq + r][((g ^ kq) * kUnits) + n] = acc[0][g][r];
-        red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r];
+        red[wave][4 * kq + r][((g ^ kq) * kUnits) + n] = acc[0][g][r] * kWScaleInv;
+        red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r] * kWScaleInv;
       }
     __syncthreads();
     if (own) {
@@ -195,16 +262,8 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_step_kernel(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const int kbase = 4 * kKL * wave + kKL * kq;
-  float wreg[4][kKL];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float* wrow = whh + ((size_t)dir * 4 * kH + (size_t)g * kH + unit0 + n) * kH + kbase;
-#pragma unroll
-    for (int s4 = 0; s4 < kKL / 4; ++s4) {
-      const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * s4);
-      wreg[g][4 * s4] = v.x; wreg[g][4 * s4 + 1] = v.y; wreg[g][4 * s4 + 2] = v.z; wreg[g][4 * s4 + 3] = v.w;
-    }
-  }
+  WFrags wf;
+  load_w_frags(whh, dir, unit0, n, kbase, wf);
   const int cb = tid >> 4, cu = tid & 15;
   const bool own = cb < B;
   const int my_off = own ? off[cb] : 0, my_len = own ? len[cb] : 0;
@@ -232,24 +291,14 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_step_kernel(const floa
   f32x4 acc[2][4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int s4 = 0; s4 < kKL / 4; ++s4) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s4][e], wreg[g][4 * s4 + e], acc[0][g], 0, 0, 0);
-      if (two_tiles) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[s4][e], wreg[g][4 * s4 + e], acc[1][g], 0, 0, 0);
-      }
-    }
-  }
+  recur_mfma(ha, wf, acc[0]);
+  if (two_tiles) recur_mfma(hb, wf, acc[1]);
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      red[wave][4 * kq + r][((g ^ kq) * kUnits) + n] = acc[0][g][r];
-      red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r];
+      red[wave][4 * kq + r][((g ^ kq) * kUnits) + n] = acc[0][g][r] * kWScaleInv;
+      red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r] * kWScaleInv;
     }
   __syncthreads();
   if (own) {

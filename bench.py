@@ -33,8 +33,10 @@ SEED_PCM = 20251114
 GEMM_ONLY_MASK = 0x101      # bit 0 = gemm class; bit 8 keeps the value != 1 (1 means 'all classes')
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (the kernel used for small launches)
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense BF16 MFMA peak
-X6_MFMAS_PER_BLOCK = 6              # gemm_x6.hip: six bf16 MFMAs per fp32 32x32x16 block (exact 3-way operand split)
+X6_MFMAS_PER_BLOCK = 6              # gemm_x6.hip: six bf16 MFMAs per fp32 32x32x16 block (exact 3-way operand split; PFHIP_GEMM_X3=0)
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / X6_MFMAS_PER_BLOCK      # 416.7 TFLOP/s of fp32-equivalent work
+X3_MFMAS_PER_BLOCK = 3              # gemm_x3.hip (default): three fp16 MFMAs per block (two fp16 planes per operand, 22-23 bits)
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / X3_MFMAS_PER_BLOCK      # 833.3 TFLOP/s of fp32-equivalent work (FP16 dense peak = BF16's)
 
 
 def synth_pcm(index: int, n: int, rng) -> np.ndarray:
@@ -66,7 +68,7 @@ def pmc_traffic():
     WRITE_SIZE, collected with rocprofv3 in separate --pmc runs of this same command); PMC counters cannot be read from
     inside the timed run, so this is the last PROFILED value — returned with the file it came from (`traffic_source`) so
     that nobody reads it as measured in this run — or (None, None) when no file is present."""
-    for rel in ("r02/pmc_hbm_traffic.json", "r01/pmc_hbm_traffic_e.json", "r01/pmc_hbm_traffic_d.json", "r01/pmc_hbm_traffic_c.json",
+    for rel in ("r03/pmc_hbm_traffic.json", "r02/pmc_hbm_traffic.json", "r01/pmc_hbm_traffic_e.json", "r01/pmc_hbm_traffic_d.json", "r01/pmc_hbm_traffic_c.json",
                 "r01/pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", rel)) as f:
@@ -399,6 +401,7 @@ def main():
     dt_host = max_over_ranks(time.perf_counter() - t0, dist, torch.device("cuda", local_rank))
     assert all(list(a) == list(b) for a, b in zip(res_h["ids"], res["ids"]))
 
+    x3 = os.environ.get("PFHIP_GEMM_X3", "1") != "0" and os.environ.get("PFHIP_GEMM_X6", "1") != "0"
     audio_per_step = world * args.batch * args.seconds
     value = audio_per_step * args.steps / dt
     tokens = int(sum(len(x) for x in res["ids"]))
@@ -408,7 +411,10 @@ def main():
             "metric": "audio-sec/sec (xRT) Paraformer-large offline, 30s utts",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (operands split exactly into 3 bf16 planes, products on the BF16 matrix cores, fp32 accumulate)",
+            "vs_baseline": None,
+            "dtype": ("f32 (operands staged as 2 fp16 planes = 22-23 significant bits, 3 products per block on the FP16 matrix cores, "
+                      "fp32 accumulate; error vs fp64 = the fp32 MFMA chain's)" if x3 else
+                      "f32 (operands split exactly into 3 bf16 planes, 6 products on the BF16 matrix cores, fp32 accumulate)"),
             "data": "synthetic",
             "value_host_buffers_in_flight": audio_per_step * args.steps / dt_host_fly,
             "ms_per_step_host_buffers_in_flight": 1e3 * dt_host_fly / args.steps,
@@ -438,15 +444,20 @@ def main():
             g = prof["gemm"]
             traffic, traffic_source = pmc_traffic()
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+            per_block = X3_MFMAS_PER_BLOCK if x3 else X6_MFMAS_PER_BLOCK
+            peak = X3_PEAK_TFLOPS if x3 else X6_PEAK_TFLOPS
             out["roofline"] = {
-                # achieved = ALGORITHMIC fp32 flops (2*M*N*K) per second; the dominant kernel executes 6 bf16 MFMAs per block,
-                # so its ceiling is the BF16 dense peak / 6 (executed MFMA rate = 6 x achieved, against 2500)
-                "bound": "mfma", "kernel": "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel", "achieved": ach, "peak": X6_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / X6_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                "note": "flops counted = 2*M*N*K of the GEMMs only; since round 2 the same launches also carry the encoder's "
-                        "LayerNorms (row statistics in the producing epilogue, normalisation on load in the consumer), so the class "
-                        "does more work per counted flop than in round 1 while the step got shorter",
-                "executed_mfma_tflops": ach * X6_MFMAS_PER_BLOCK, "executed_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+                # achieved = ALGORITHMIC fp32 flops (2*M*N*K) per second; the dominant kernel executes 3 fp16 MFMAs per block (6 bf16
+                # ones with PFHIP_GEMM_X3=0), so its ceiling is the FP16 / BF16 dense peak / 3 (/ 6); executed MFMA rate = 3 x achieved
+                "bound": "mfma",
+                "kernel": "gemm_f32_f16x3_128_kernel / gemm_f32_f16x3_kernel" if x3 else "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+                "note": "flops counted = 2*M*N*K of the GEMMs only (the same launches also carry the LayerNorms folded into them). "
+                        "Round 3 halved the MFMAs per block (3 fp16 products instead of 6 bf16 ones: ceiling 417 -> 833 TFLOP/s): the "
+                        "class takes 0.7 x the time and `frac` is quoted against the NEW ceiling; against round 2's it would read "
+                        f"{ach / X6_PEAK_TFLOPS:.3f}" if x3 else "six bf16 products per block (PFHIP_GEMM_X3=0)",
+                "frac_of_round2_ceiling_417": ach / X6_PEAK_TFLOPS,
+                "executed_mfma_tflops": ach * per_block, "executed_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": F32_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches_per_step": g["launches"] / args.steps,
                 "flops_per_launch": g["flops"] / max(1, g["launches"]),

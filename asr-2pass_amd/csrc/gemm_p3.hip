@@ -1,0 +1,393 @@
+// fp32-grade GEMM on PRE-SPLIT operands: the three-product fp16 scheme of gemm_x3.hip with the split taken out of the K-loop.
+//
+// gemm_x3.hip stages fp32 operands through registers and splits them into two fp16 planes on the way into LDS.  With three MFMAs per
+// block that staging — not the matrix cores — bounds the kernel: timing-only builds of its 256 x 128 tile at K = 2048 run 110 us as
+// built, 64 us without the split and its LDS writes, 60 us with MFMAs alone; replacing the split by a plain 16-byte register copy
+// changes nothing (so it is the global -> VGPR -> LDS traffic, not the arithmetic).  Here both operands ARRIVE as plane images:
+//   * weights are split once at load (launch_split_planes), pre-multiplied by their power-of-two scale;
+//   * activations are written as planes by the kernel that produces them (this kernel's epilogue, the attention's) — 2 + 2 bytes
+//     per element, the bytes of the fp32 value they replace;
+// and the K-loop is LDS-DMA (`global_load_lds_dwordx4`: global -> LDS, no VGPR, no ds_write, no vector instruction), fragment
+// reads and MFMAs.
+//
+// Plane image of a matrix X[rows, K] (rows padded to 128): for each plane, [K / 16][rows][16] fp16 — the 32 bytes of one row's
+// K-step are contiguous, the rows of a K-step are contiguous, so the 128 rows x 16 k of a tile's K-step are ONE 4-KB run per plane
+// that four wave-instructions copy into LDS verbatim.  The two 16-byte halves of a row are swapped where row bit 3 is set: the LDS
+// image is then conflict-free for `ds_read_b128` on unpadded 32-byte rows (16 lanes = 16 rows read 16 distinct 16-byte slots of
+// the 256-byte bank row), and the swizzle costs nothing because it is baked into the image.
+//
+// Tile 128 x 128, 4 waves as 2 x 2 (each 64 x 64 = four MFMA tiles, twelve MFMAs per K-step), two workgroups per CU, ring of FOUR
+// 16-KB stages: step k multiplies fragments it holds, reads the fragments of stage k + 1, and issues the DMA of K-step k + 4 into the
+// stage it has just finished reading; `s_waitcnt vmcnt(8)` + the step barrier retire K-step k + 2's DMA two full steps after issue.
+// Epilogues: fp32 C (bias, LayerNorm-fold finish, residual, ReLU, row statistics — as gemm_x3.hip), plane images of C for the
+// next GEMM, or both.
+#include "kernels.h"
+
+#include <algorithm>
+#include <atomic>
+
+namespace pfhip {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using float2v = __attribute__((ext_vector_type(2))) float;
+
+constexpr int kPM = 128, kPN = 128, kPK = 16;
+constexpr int kPRowB = 32;                              // bytes of one (row, K-step) of one plane
+constexpr int kPPlane = 128 * kPRowB;                   // 4,096 B: one plane of one operand of one stage
+constexpr int kPStage = 4 * kPPlane;                    // A hi | A lo | W hi | W lo = 16,384 B
+constexpr int kPRing = 4;
+constexpr int kPCs = kPN + 4;                           // padded C-tile row stride (floats)
+constexpr int kPLds = kPM * kPCs * 4 + kPM * 8;         // 68,608 B: the C tile + row statistics (> 4 stages = 65,536 B)
+static_assert(kPRing * kPStage <= kPLds, "the ring must fit");
+
+__device__ __forceinline__ float sub_lo(float x, unsigned h) {      // x - (float)low half of h: one instruction, exact
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float sub_hi(float x, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+// eight consecutive values -> 16 bytes of the hi plane and 16 bytes of the lo plane (hi = rtz, lo = rn(x - hi))
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  unsigned* hp = &hi.x;
+  unsigned* lp = &lo.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hp[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]));
+    const float2v r = {sub_lo(v[2 * i], hp[i]), sub_hi(v[2 * i + 1], hp[i])};
+    lp[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
+  }
+}
+// byte offset of (row, 8-k piece) inside a plane image with `rows` rows per K-step
+__device__ __forceinline__ size_t image_off(int kstep, int row, int piece, int rows) {
+  return ((size_t)kstep * rows + row) * kPRowB + (size_t)((piece ^ ((row >> 3) & 1)) << 4);
+}
+
+// X[rows_valid, K] fp32 (row stride ld) -> plane images; rows >= rows_valid are written as zeros.  One thread per (row, 8-k piece).
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ X, int ld, int rows_valid, int rows, int K, float scale,
+                                                           unsigned char* __restrict__ hi, unsigned char* __restrict__ lo) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int pieces = K / 8;
+  if (idx >= (size_t)rows * pieces) return;
+  // consecutive threads walk the rows of one piece: the image writes of a wave are contiguous in pairs of 16 B
+  const int row = (int)(idx % rows), pc = (int)(idx / rows);
+  float v[8];
+  if (row < rows_valid) {
+    const float4 a = *reinterpret_cast<const float4*>(X + (size_t)row * ld + 8 * pc);
+    const float4 b = *reinterpret_cast<const float4*>(X + (size_t)row * ld + 8 * pc + 4);
+    v[0] = a.x * scale; v[1] = a.y * scale; v[2] = a.z * scale; v[3] = a.w * scale;
+    v[4] = b.x * scale; v[5] = b.y * scale; v[6] = b.z * scale; v[7] = b.w * scale;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  }
+  uint4 h, l;
+  split8(v, h, l);
+  const size_t off = image_off(pc >> 1, row, pc & 1, rows);
+  *reinterpret_cast<uint4*>(hi + off) = h;
+  *reinterpret_cast<uint4*>(lo + off) = l;
+}
+
+__device__ __forceinline__ void tile_of_block_p3(int bid, int n_tiles, int tiles_n, int gw, int& tm, int& tn) {
+  {
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tiles_m = n_tiles / tiles_n, full = tiles_n / gw, span = tiles_m * gw;
+  if (bid < full * span) {
+    const int g = bid / span, j = bid - g * span;
+    tm = j / gw; tn = g * gw + (j - tm * gw);
+  } else {
+    const int j = bid - full * span, w = tiles_n - full * gw;
+    tm = j / w; tn = full * gw + (j - tm * w);
+  }
+}
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  v += __shfl_xor(v, 16);
+  return v;
+}
+__device__ __forceinline__ void tile_row_stats(const float4& v, int grow, int M, int tn, int tiles_n, int c4, float* __restrict__ stats) {
+  const float sum = half_wave_sum((v.x + v.y) + (v.z + v.w));
+  const float mean = sum * (1.0f / kPN);
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+  const float q = half_wave_sum((a * a + b * b) + (c * c + d * d));
+  if (c4 == 0 && grow < M) *reinterpret_cast<float2*>(stats + ((size_t)grow * tiles_n + tn) * 2) = make_float2(mean, q);
+}
+__device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, int tiles, float eps, int row) {
+  const float* sp = stats + (size_t)row * tiles * 2;
+  float msum = 0.f, m2 = 0.f;
+  for (int t = 0; t < tiles; ++t) msum += sp[2 * t];
+  const float mean = msum / (float)tiles;
+  for (int t = 0; t < tiles; ++t) { const float dm = sp[2 * t] - mean; m2 += sp[2 * t + 1] + (float)kPN * dm * dm; }
+  return make_float2(mean, 1.0f / sqrtf(m2 / (float)(tiles * kPN) + eps));
+}
+
+// OUT: 1 = fp32 C, 2 = plane images of C, 3 = both.  A / W images: rows_a / rows_w rows per K-step.  inv_scale = 1 / (weight scale).
+// FOUR waves (2 x 2, each 64 x 64 = four MFMA tiles, twelve MFMAs and eight fragment reads per K-step: 0.67 KB of LDS reads per
+// MFMA; the first form of this kernel — eight waves of 64 x 32, 1 KB per MFMA — ran 8-20 % over gemm_x3.hip and was bound by the
+// LDS reads), two workgroups per CU.
+constexpr int kPThreads = 256;
+template <bool LN, int OUT>
+__global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
+    const unsigned char* __restrict__ Ah, const unsigned char* __restrict__ Al, int rows_a, const unsigned char* __restrict__ Wh,
+    const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
+    int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
+    const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
+    float inv_scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  int tm, tn;
+  tile_of_block_p3(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
+  const int m0 = tm * kPM, n0 = tn * kPN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // DMA map: per K-step the block copies 16 chunks of 1 KB (4 regions x 4 chunks of 32 rows); wave w moves rows 32 w .. 32 w + 31
+  // of all four regions (A hi, A lo, W hi, W lo)
+  const size_t ka = (size_t)rows_a * kPRowB, kw = (size_t)rows_w * kPRowB;      // bytes per K-step of an image
+  const unsigned char* const gah = Ah + ((size_t)(m0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gal = Al + ((size_t)(m0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gwh = Wh + ((size_t)(n0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gwl = Wl + ((size_t)(n0 + 32 * wave)) * kPRowB + lane * 16;
+  const int lds_c = wave * 1024;
+#ifndef PFHIP_P3_ABLATE
+#define PFHIP_P3_ABLATE 0      // timing-only builds (tools/x3_variant.sh): 1 no step barrier, 2 no DMA, 3 no fragment reads, 4 MFMAs only
+#endif
+#define PFHIP_DMA1(src, stage, region)                                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                              \
+                                   (__attribute__((address_space(3))) void*)(lds + (stage) * kPStage + (region) * kPPlane + lds_c), 16, 0, 0);
+#define PFHIP_DMA(stage, ks)                                                                                          \
+  PFHIP_DMA1(gah + (size_t)(ks) * ka, stage, 0) PFHIP_DMA1(gal + (size_t)(ks) * ka, stage, 1)                         \
+  PFHIP_DMA1(gwh + (size_t)(ks) * kw, stage, 2) PFHIP_DMA1(gwl + (size_t)(ks) * kw, stage, 3)
+
+  // fragment addresses (row R of the tile, 8-k piece h, swizzled like the image): rows R and R + 32 share bit 3
+  const int ra = wr * 64 + r, rb = wc * 64 + r;
+  const int a_fr = ra * kPRowB + ((h ^ ((ra >> 3) & 1)) << 4);
+  const int w_fr = 2 * kPPlane + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
+
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (LN && tid < kPM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+  half8 fa[2][2], fb[2][2], ga_[2][2], gb_[2][2];          // [plane][tile]
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_M(acc, A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0); PFHIP_SB;
+#define PFHIP_RA(G, st, p, i) if (PFHIP_P3_ABLATE < 3) G[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kPStage + (p) * kPPlane + a_fr + (i) * 32 * kPRowB));
+#define PFHIP_RB(G, st, p, i) if (PFHIP_P3_ABLATE < 3) G[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kPStage + (p) * kPPlane + w_fr + (i) * 32 * kPRowB));
+  // step: fragments FA / FB hold K-step k; read K-step k + 1 from stage `rst` into GA / GB; DMA K-step `kdma` into stage `wst`.
+  // Per accumulator: a_hi w_lo, a_lo w_hi, a_hi w_hi (the order of gemm_x3.hip).
+#define PFHIP_STEP(FA, FB, GA, GB, wst, rst, kdma)                                                                    \
+  {                                                                                                                   \
+    if (PFHIP_P3_ABLATE != 2 && PFHIP_P3_ABLATE != 4) { PFHIP_DMA(wst, kdma) } PFHIP_SB;                              \
+    PFHIP_M(acc00, FA[0][0], FB[1][0]) PFHIP_RA(GA, rst, 0, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc01, FA[0][0], FB[1][1]) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc10, FA[0][1], FB[1][0]) PFHIP_RA(GA, rst, 0, 1) PFHIP_SB;                                              \
+    PFHIP_M(acc11, FA[0][1], FB[1][1]) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                                              \
+    PFHIP_M(acc00, FA[1][0], FB[0][0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc01, FA[1][0], FB[0][1]) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc10, FA[1][1], FB[0][0]) PFHIP_RA(GA, rst, 1, 1) PFHIP_SB;                                              \
+    PFHIP_M(acc11, FA[1][1], FB[0][1]) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                                              \
+    PFHIP_M(acc00, FA[0][0], FB[0][0])                                                                                \
+    PFHIP_M(acc01, FA[0][0], FB[0][1])                                                                                \
+    PFHIP_M(acc10, FA[0][1], FB[0][0])                                                                                \
+    PFHIP_M(acc11, FA[0][1], FB[0][1])                                                                                \
+    if (PFHIP_P3_ABLATE == 1 || PFHIP_P3_ABLATE == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     \
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+    PFHIP_SB;                                                                                                         \
+  }
+
+  const int nk = K / kPK;
+  auto kclamp = [&](int t) { return t < nk ? t : nk - 1; };
+  PFHIP_DMA(0, 0)
+  PFHIP_DMA(1, kclamp(1))
+  PFHIP_DMA(2, kclamp(2))
+  PFHIP_DMA(3, kclamp(3))
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
+  PFHIP_RA(fa, 0, 0, 0) PFHIP_RA(fa, 0, 0, 1) PFHIP_RA(fa, 0, 1, 0) PFHIP_RA(fa, 0, 1, 1)
+  PFHIP_RB(fb, 0, 0, 0) PFHIP_RB(fb, 0, 0, 1) PFHIP_RB(fb, 0, 1, 0) PFHIP_RB(fb, 0, 1, 1)
+  if (PFHIP_P3_ABLATE >= 3) {          // timing-only builds: defined register contents
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + p * kPPlane + a_fr + i * 32 * kPRowB));
+        fb[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + p * kPPlane + w_fr + i * 32 * kPRowB));
+        ga_[p][i] = fa[p][i]; gb_[p][i] = fb[p][i];
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // stage 0 is free for the DMA of K-step 4
+  // step k: fragments f / g by parity; DMA K-step k + 4 into stage k % 4 (whose fragments this step holds in registers); read stage
+  // (k + 1) % 4.  A DMA has TWO full steps to land (memory latency under load is longer than one step: the three-stage form of this
+  // loop waited on vmcnt every step).
+#define PFHIP_S0(kt) PFHIP_STEP(fa, fb, ga_, gb_, 0, 1, kclamp((kt) + 4))
+#define PFHIP_S1(kt) PFHIP_STEP(ga_, gb_, fa, fb, 1, 2, kclamp((kt) + 5))
+#define PFHIP_S2(kt) PFHIP_STEP(fa, fb, ga_, gb_, 2, 3, kclamp((kt) + 6))
+#define PFHIP_S3(kt) PFHIP_STEP(ga_, gb_, fa, fb, 3, 0, kclamp((kt) + 7))
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 4) { PFHIP_S0(kt) PFHIP_S1(kt) PFHIP_S2(kt) PFHIP_S3(kt) }
+  if (kt < nk) PFHIP_S0(kt)
+  if (kt + 1 < nk) PFHIP_S1(kt)
+  if (kt + 2 < nk) PFHIP_S2(kt)
+#undef PFHIP_S0
+#undef PFHIP_S1
+#undef PFHIP_S2
+#undef PFHIP_S3
+#undef PFHIP_STEP
+#undef PFHIP_M
+#undef PFHIP_RA
+#undef PFHIP_RB
+#undef PFHIP_DMA
+#undef PFHIP_DMA1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last (redundant) DMAs must not land in the C tile
+  __syncthreads();
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------------
+  float* const Cs = reinterpret_cast<float*>(lds);
+  {
+    float* cw = Cs + (wr * 64 + 4 * h) * kPCs + wc * 64 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ro = ((e & 3) + 8 * (e >> 2)) * kPCs;
+      cw[ro] = acc00[e];
+      cw[ro + 32] = acc01[e];
+      cw[ro + 32 * kPCs] = acc10[e];
+      cw[ro + 32 * kPCs + 32] = acc11[e];
+    }
+  }
+  float2* const s_mr = reinterpret_cast<float2*>(lds + kPM * kPCs * 4);
+  if (LN && tid < kPM) s_mr[tid] = ln_mr;
+  __syncthreads();
+
+  if (OUT & 1) {      // fp32 rows: 32 lanes x 16 B per row; the final values go back into the LDS tile when planes follow
+    const int c4 = tid & 31, rsub = tid >> 5;
+    const int gcol = n0 + 4 * c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
+    if (bias && gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
+    float4 r1v[16];                                          // the residual rows of the tile, requested in one go
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+      const int grow = m0 + pass * 8 + rsub;
+      r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+      const int row = pass * 8 + rsub, grow = m0 + row;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * kPCs + 4 * c4);
+      v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
+      if (LN) {
+        const float2 mr = s_mr[row];
+        v.x = mr.y * (v.x - mr.x * cs4.x); v.y = mr.y * (v.y - mr.x * cs4.y); v.z = mr.y * (v.z - mr.x * cs4.z); v.w = mr.y * (v.w - mr.x * cs4.w);
+      }
+      v.x += bv.x + r1v[pass].x; v.y += bv.y + r1v[pass].y; v.z += bv.z + r1v[pass].z; v.w += bv.w + r1v[pass].w;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
+      if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
+    }
+    if (OUT & 2) __syncthreads();
+  }
+  if (OUT & 2) {      // plane images of C: thread = (row, K-step of the consumer): 64 lanes = 64 consecutive rows = 2 KB per plane, contiguous
+    const int row = tid & 127, grow = m0 + row;
+    const float2 mr = (LN && OUT == 2) ? s_mr[row] : make_float2(0.f, 1.f);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = (tid >> 7) + 2 * jj;                    // 16-column group of the tile
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(Cs + row * kPCs + 16 * j + 4 * c);
+        v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+      }
+      if (OUT == 2) {     // planes only: the epilogue arithmetic happens here (the fp32 pass did not run)
+        const int gc = n0 + 16 * j;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 s4 = LN ? *reinterpret_cast<const float4*>(ln_colsum + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[4 * c + e] * inv_scale;
+            if (LN) x = mr.y * (x - mr.x * ss[e]);
+            x += bb[e];
+            if (relu) x = fmaxf(x, 0.f);
+            v[4 * c + e] = x;
+          }
+        }
+      }
+      const int ksp = (n0 >> 4) + j;                        // K-step of the consumer this column group is
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const float w8[8] = {v[8 * pc], v[8 * pc + 1], v[8 * pc + 2], v[8 * pc + 3], v[8 * pc + 4], v[8 * pc + 5], v[8 * pc + 6], v[8 * pc + 7]};
+        uint4 hh, ll;
+        split8(w8, hh, ll);
+        const size_t off = image_off(ksp, grow, pc, rows_p);
+        *reinterpret_cast<uint4*>(Ph + off) = hh;
+        *reinterpret_cast<uint4*>(Pl + off) = ll;
+      }
+    }
+  }
+}
+
+template <auto kern, class... Args>
+void launch_with_lds(int n_tiles, int lds_bytes, hipStream_t s, Args... args) {
+  static std::atomic<unsigned long long> attr_done{0};      // > 64 KB of dynamic LDS needs the opt-in once per kernel and device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_done.load(std::memory_order_relaxed) >> (dev & 63) & 1ull)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kPThreads), lds_bytes, s, args...);
+}
+
+}  // namespace
+
+size_t plane_image_bytes(int rows, int K) { return (size_t)((rows + 127) / 128 * 128) * (size_t)K * 2; }
+
+void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K, float scale, void* hi, void* lo, hipStream_t s) {
+  if (rows <= 0 || K <= 0) return;
+  const size_t n = (size_t)rows * (K / 8);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, ld, rows_valid, rows, K, scale,
+                     static_cast<unsigned char*>(hi), static_cast<unsigned char*>(lo));
+}
+
+void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
+                    void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
+                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s) {
+  if (M <= 0 || N <= 0) return;
+  const int tiles_n = (N + kPN - 1) / kPN, n_tiles = ((M + kPM - 1) / kPM) * tiles_n;
+  gw = std::max(1, std::min(gw, tiles_n));
+  const int out = (C ? 1 : 0) | (Ph ? 2 : 0);
+  const float inv = 1.0f / w_scale;
+  const unsigned char *ah = static_cast<const unsigned char*>(Ah), *al = static_cast<const unsigned char*>(Al);
+  const unsigned char *wh = static_cast<const unsigned char*>(Wh), *wl = static_cast<const unsigned char*>(Wl);
+  unsigned char *ph = static_cast<unsigned char*>(Ph), *pl = static_cast<unsigned char*>(Pl);
+#define PFHIP_P3(LNF, OUTM)                                                                                                     \
+  launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+                                                 M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv)
+  if (ln_stats) {
+    if (out == 1) PFHIP_P3(true, 1); else if (out == 2) PFHIP_P3(true, 2); else PFHIP_P3(true, 3);
+  } else {
+    if (out == 1) PFHIP_P3(false, 1); else if (out == 2) PFHIP_P3(false, 2); else PFHIP_P3(false, 3);
+  }
+#undef PFHIP_P3
+}
+
+}  // namespace pfhip

@@ -31,6 +31,8 @@
 
 // Timing-only ablations of the K-step (tools/x3_ablate.sh builds one library per value; results are WRONG for any value but 0):
 //   1 no s_barrier   2 no split / LDS writes   3 no fragment reads   4 no global loads   5 MFMAs only (2 + 3 + 4, barrier kept)
+//   6 staging as a plain copy (one 16-byte LDS write per float4, no split arithmetic): the cost model of operands that arrive
+//     pre-split from their producers
 #ifndef PFHIP_X3_ABLATE
 #define PFHIP_X3_ABLATE 0
 #endif
@@ -96,6 +98,11 @@ __device__ __forceinline__ void split2(const float4& v, float scale, unsigned ch
 struct SplitTmp { float r0, r1, r2, r3; };
 template <bool SC>
 __device__ __forceinline__ void split_hi(const float4& v, float scale, unsigned char* dst, SplitTmp& t) {
+#if PFHIP_X3_ABLATE == 6
+  *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(reinterpret_cast<uintptr_t>(dst) & ~(uintptr_t)15)) = v;
+  t.r0 = t.r1 = t.r2 = t.r3 = 0.f;
+  return;
+#endif
   const float x0 = SC ? v.x * scale : v.x, x1 = SC ? v.y * scale : v.y, x2 = SC ? v.z * scale : v.z, x3 = SC ? v.w * scale : v.w;
   const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
   const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x2, x3));
@@ -103,6 +110,9 @@ __device__ __forceinline__ void split_hi(const float4& v, float scale, unsigned 
   t.r0 = sub_lo(x0, h01); t.r1 = sub_hi(x1, h01); t.r2 = sub_lo(x2, h23); t.r3 = sub_hi(x3, h23);
 }
 __device__ __forceinline__ void split_lo(unsigned char* dst, const SplitTmp& t) {
+#if PFHIP_X3_ABLATE == 6
+  return;
+#endif
   const float2v r01 = {t.r0, t.r1}, r23 = {t.r2, t.r3};
   *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r01, half2v)),
                                               __builtin_bit_cast(unsigned, __builtin_convertvector(r23, half2v)));

@@ -68,6 +68,16 @@ void launch_gemm_f32_bf16x6(const float* A, int lda, const float* W, int ldw, fl
 void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,
                            const float* ln_stats, int ln_tiles, float* stats_out, bool half_tile, const float* ln_colsum, float sw);
+// ---- pre-split operands (gemm_p3.hip): the three-product fp16 scheme with the split taken out of the K-loop -------------------
+// Plane image of X[rows, K]: two arrays (hi, lo) of plane_image_bytes(rows, K) bytes each, laid out [K / 16][rows padded to 128][16]
+// fp16 with the 16-byte halves of a row swapped where row bit 3 is set.  launch_split_planes writes the images of an fp32 matrix
+// (times `scale`); launch_gemm_p3 multiplies A images by W images (N % 128 == 0, K % 16 == 0; W pre-multiplied by w_scale) and
+// writes fp32 C (bias, LayerNorm-fold finish, residual R1, ReLU, row statistics) and / or the plane images of C (rows_p rows).
+size_t plane_image_bytes(int rows, int K);
+void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K, float scale, void* hi, void* lo, hipStream_t s);
+void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
+                    void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
+                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s);
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).

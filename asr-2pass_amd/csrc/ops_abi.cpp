@@ -79,6 +79,21 @@ int pfhip_op_gemm_f32_scaled(const float* A, int lda, const float* W, int ldw, f
 }
 float pfhip_op_best_w_scale(float max_abs) { return pfhip::best_w_scale(max_abs); }
 
+size_t pfhip_op_plane_image_bytes(int rows, int K) { return pfhip::plane_image_bytes(rows, K); }
+int pfhip_op_split_planes(const float* X, int ld, int rows_valid, int rows, int K, float scale, void* hi, void* lo, void* stream) {
+  if (K % 16 || rows % 128 || rows_valid > rows) return (int)hipErrorInvalidValue;
+  pfhip::launch_split_planes(X, ld, rows_valid, rows, K, scale, hi, lo, S(stream));
+  return (int)hipGetLastError();
+}
+int pfhip_op_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
+                     void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, int relu,
+                     const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, void* stream) {
+  if (K % 16 || N % 128 || rows_a % 128 || rows_w % 128 || (!C && !Ph) || !(w_scale > 0.f)) return (int)hipErrorInvalidValue;
+  pfhip::launch_gemm_p3(Ah, Al, rows_a, Wh, Wl, rows_w, w_scale, C, ldc, Ph, Pl, rows_p, bias, R1, ldr1, M, N, K, relu != 0, ln_stats, ln_tiles,
+                        ln_colsum, stats_out, 4, S(stream));
+  return (int)hipGetLastError();
+}
+
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream) {
   if (D % 4 || Dout % 4 || Dout > 2048 || D > Dout) return (int)hipErrorInvalidValue;

@@ -191,3 +191,52 @@ def logsoftmax_argmax(logits, V=None, want_logp=True):
     ids = torch.empty(ML, dtype=torch.int32, device=logits.device)
     _ck(_lib().pfhip_op_logsoftmax_argmax(_p(logits), logits.stride(0), ML, V, _p(logp), _p(ids), _stream()), "logsoftmax")
     return logp, ids
+
+
+# ---- pre-split operands (csrc/gemm_p3.hip) ------------------------------------------------------------------------------------
+def split_planes(X, rows=None, scale=1.0, rows_valid=None):
+    """fp32 [R, K] (device) -> (hi, lo) plane images (uint8 tensors of plane_image_bytes each), rows padded to a multiple of 128."""
+    lib = _lib()
+    R, K = X.shape
+    rows_valid = R if rows_valid is None else rows_valid
+    rows = round_up(R if rows is None else rows, 128)
+    lib.pfhip_op_plane_image_bytes.restype = ctypes.c_size_t
+    lib.pfhip_op_plane_image_bytes.argtypes = [_ci, _ci]
+    nb = int(lib.pfhip_op_plane_image_bytes(rows, K))
+    hi = torch.empty(nb, dtype=torch.uint8, device=X.device)
+    lo = torch.empty(nb, dtype=torch.uint8, device=X.device)
+    lib.pfhip_op_split_planes.argtypes = [_vp, _ci, _ci, _ci, _ci, ctypes.c_float, _vp, _vp, _vp]
+    _ck(lib.pfhip_op_split_planes(_p(X), X.stride(0), rows_valid, rows, K, float(scale), _p(hi), _p(lo), _stream()), "split_planes")
+    return hi, lo, rows
+
+
+def planes_to_float(hi, lo, rows, K):
+    """Inverse of the image layout (host side, for tests): -> float64 [rows, K] = hi + lo."""
+    import numpy as np
+    out = np.zeros((rows, K), np.float64)
+    for img in (hi, lo):
+        a = img.cpu().numpy().view(np.float16).reshape(K // 16, rows, 2, 8).astype(np.float64)
+        swap = ((np.arange(rows) >> 3) & 1).astype(bool)
+        a[:, swap] = a[:, swap][:, :, ::-1]
+        out += a.transpose(1, 0, 2, 3).reshape(rows, K)
+    return out
+
+
+def gemm_p3(A_img, W_img, M, N, K, w_scale=1.0, bias=None, R1=None, relu=False, want_c=True, want_planes=False, ln_stats=None,
+            ln_tiles=0, ln_colsum=None, stats_out=None):
+    """A_img / W_img: (hi, lo, rows) from split_planes.  Returns (C or None, (hi, lo, rows) of C or None)."""
+    lib = _lib()
+    ah, al, ra = A_img
+    wh, wl, rw = W_img
+    Mp = round_up(M, 128)
+    C = torch.empty((Mp, N), dtype=torch.float32, device=ah.device) if want_c else None
+    P = None
+    if want_planes:
+        nb = int(lib.pfhip_op_plane_image_bytes(Mp, N))
+        P = (torch.zeros(nb, dtype=torch.uint8, device=ah.device), torch.zeros(nb, dtype=torch.uint8, device=ah.device), Mp)
+    lib.pfhip_op_gemm_p3.argtypes = [_vp, _vp, _ci, _vp, _vp, _ci, ctypes.c_float, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _ci,
+                                     _vp, _ci, _vp, _vp, _vp]
+    _ck(lib.pfhip_op_gemm_p3(_p(ah), _p(al), ra, _p(wh), _p(wl), rw, float(w_scale), _p(C), N if want_c else 0, _p(P[0]) if P else None,
+                             _p(P[1]) if P else None, Mp, _p(bias), _p(R1), R1.stride(0) if R1 is not None else 0, M, N, K,
+                             1 if relu else 0, _p(ln_stats), ln_tiles, _p(ln_colsum), _p(stats_out), _stream()), "gemm_p3")
+    return C, P

@@ -339,6 +339,47 @@ def test_gemm_f16_split_stated_domain(ops):
         assert rel[128:].max() < 2.0 ** -13, (kind, rel[128:].max())
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(300, 512, 512, False), (1000, 256, 2048, True), (128, 128, 16, False), (257, 1536, 576, True)])
+def test_gemm_on_pre_split_operands(ops, M, N, K, relu):
+    """gemm_p3.hip: both operands arrive as fp16 plane images (split once: weights at load, activations by their producer), the
+    K-loop is LDS-DMA + fragment reads + three MFMAs per block.  fp32 output and plane output (decoded on the host) against fp64,
+    at the accuracy of the in-loop-split kernels; the images themselves round-trip to 22+ bits."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R1 = rng.standard_normal((M, N)).astype(np.float32)
+    ws = ops.best_w_scale(float(np.abs(W).max()))
+    a_img = ops.split_planes(dev(A))
+    w_img = ops.split_planes(dev(W), scale=ws)
+    back = ops.planes_to_float(a_img[0], a_img[1], a_img[2], K)[:M]
+    assert np.abs(back - A).max() <= 2.0 ** -22 * np.abs(A).max() + 2.0 ** -24
+    assert np.abs(ops.planes_to_float(a_img[0], a_img[1], a_img[2], K)[M:]).max() == 0 if a_img[2] > M else True
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + R1
+    if relu:
+        ref = np.maximum(ref, 0)
+    Mp = (M + 127) // 128 * 128
+    dR1 = dev(np.pad(R1, ((0, Mp - M), (0, 0))))
+    tol = 3e-5 * max(1.0, np.sqrt(K / 512))
+    C, P = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dR1, relu=relu, want_c=True, want_planes=True)
+    assert np.abs(C.cpu().numpy()[:M] - ref).max() < tol
+    pl = ops.planes_to_float(P[0], P[1], P[2], N)[:M]
+    assert np.abs(pl - ref).max() < tol + 2.0 ** -21 * np.abs(ref).max()
+    C1, _ = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dR1, relu=relu, want_c=True, want_planes=False)
+    assert np.array_equal(C1.cpu().numpy()[:M], C.cpu().numpy()[:M])
+    ref2 = A.astype(np.float64) @ W.astype(np.float64).T + bias              # planes only: no residual (FFN1's form)
+    if relu:
+        ref2 = np.maximum(ref2, 0)
+    _, P2 = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), relu=relu, want_c=False, want_planes=True)
+    assert np.abs(ops.planes_to_float(P2[0], P2[1], P2[2], N)[:M] - ref2).max() < tol + 2.0 ** -21 * np.abs(ref2).max()
+    # chaining: the plane output of one GEMM is the A operand of the next
+    if N % 16 == 0 and N <= 2048:
+        W2 = (rng.standard_normal((128, N)) / np.sqrt(N)).astype(np.float32)
+        ws2 = ops.best_w_scale(float(np.abs(W2).max()))
+        C3, _ = ops.gemm_p3(P2, ops.split_planes(dev(W2), scale=ws2), M, 128, N, w_scale=ws2)
+        assert np.abs(C3.cpu().numpy()[:M] - ref2 @ W2.astype(np.float64).T).max() < 2 * tol * max(1.0, np.sqrt(N / 512)) * max(1.0, np.abs(ref2).max() / 4)
+
+
 def test_gemm_bf16_split_stated_domain(ops):
     """Where the three-plane split (gemm_x6.hip: rest(x) = x - top16(x)) stops being an fp32 GEMM, pinned:
       * a non-finite operand: Inf - Inf = NaN in the second plane, so EVERY output of that row is NaN (an fp32 GEMM would carry

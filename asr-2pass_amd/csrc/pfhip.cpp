@@ -1301,8 +1301,9 @@ pfhip_status pfhip_offline_forward(pfhip_model* head, const float* const* pcm, c
   for (int i = 0; i < batch; ++i)
     if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return fail(PFHIP_ERR_ARG, "bad pcm buffer");
   // merged with whoever else is calling (plain and timestamp models; hotwords are per connection, so contextual calls are not)
-  if (head->batch_wait_us > 0 && !head->cfg.contextual && batch < head->batch_max_utts)
-    return forward_batched(head, pcm, n_samples, batch, out);
+  bool merge;
+  { std::lock_guard<std::mutex> l(head->bq.mu); merge = head->batch_wait_us > 0 && batch < head->batch_max_utts; }
+  if (merge && !head->cfg.contextual) return forward_batched(head, pcm, n_samples, batch, out);
   pfhip_model* m = acquire_slot(head);                  // the least-loaded execution slot (context / GPU)
   tl_last_replica = m;
   const pfhip_status st = forward_direct(m, pcm, n_samples, batch, hw_emb, n_hotwords, out);

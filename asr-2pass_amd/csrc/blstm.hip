@@ -33,7 +33,7 @@ constexpr int kXcds = 8;
 constexpr int kBlstmThreads = 512;   // 8 waves split K = 512 eight ways: 16 consecutive k per lane
 constexpr int kWaves = kBlstmThreads / 64;
 constexpr int kKL = kH / kWaves / 4;  // k per lane (4 lane groups per wave)
-// barrier words after the exchange buffer: [0],[1] step counters, [2] error flag, [4],[5] XCC id + 1 of each direction
+// state words after the exchange ring: [2] error flag, [4],[5] XCC id + 1 of each direction ([0],[1] unused)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -137,11 +137,30 @@ __device__ __forceinline__ void load16_l2(const float* p, f32x4& a, f32x4& b, f3
       : "memory");
 }
 static_assert(kH / (kBlstmThreads / 64) / 4 == 16, "load16_l2 moves exactly one lane's K slice");
+static_assert(kBlstmScratchFloats == 2 * 4 * kMaxB * kH + 8 && kBlstmFlagWord == 2 * 4 * kMaxB * kH + 2, "kernels.h states the scratch layout");
 
 // gx   [rows, 2*4H]  input projections + biases, forward gates then backward gates (i,f,g,o blocks of H each)
 // whh  [2][4H][H]
 // y    [rows, 2H]    forward h | backward h
-// hx   [2 dir][2 parity][kMaxB][H]  exchange buffer, zeroed by the host; bar = kBarWords words, zeroed
+// hx   [2 dir][kRing][kMaxB][H]  exchange ring; the host fills buffer 0 with zeros (h_0) and the others with the sentinel
+//
+// THE EXCHANGE CARRIES ITS OWN SYNCHRONISATION.  Round 2's step ended in a barrier (stores acknowledged -> atomic counter -> spin
+// -> load h: four L2 round trips in a row on a chain of 1500 steps).  Here a block publishes its 16 x 32 values of h(t) with plain
+// stores into ring buffer (t + 1) % 4 and the readers POLL the data: every cell of a buffer holds the sentinel (+inf; |h| < 1)
+// until its value arrives, each lane re-reads its own 64 or 128 bytes until none of them is the sentinel.  One store -> L2 -> load
+// hand-off per step.  The ring has FOUR buffers so that the reset needs no wait of its own:
+//   step t: poll buffer t % 4 (h(t-1), complete once the poll ends) -> reset my cells of buffer (t + 3) % 4 to the sentinel (it
+//   held h(t-2), which every block finished reading before it published h(t-1), and I have just seen every h(t-1)) -> compute
+//   -> publish h(t) into buffer (t + 1) % 4.
+//   A reader polls buffer (t + 3) % 4 at step t + 3, after it saw my h(t+1); I issued h(t+1) after my poll of step t + 1, whose
+//   `s_waitcnt vmcnt(0)` also waited for the acknowledgement of the reset of step t: the reset is in L2 before any reader can look,
+//   so nobody ever takes h(t-2) for h(t+2).
+constexpr int kRing = 4;
+constexpr unsigned kSentinelBits = 0x7f800000u;          // +inf
+constexpr unsigned kSpinLimit = 1u << 16;                // ~0.1 s of polling, then the error flag (the host redoes the call stepwise)
+
+__device__ __forceinline__ float max4(const f32x4& v) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
+
 __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                        float* __restrict__ y, float* hx, unsigned* bar,
                                                        const int* __restrict__ off, const int* __restrict__ len, int B,
@@ -160,42 +179,72 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
   // B fragments (two fp16 planes, resident for the whole sequence): n-tile g = gate g, column n = unit n of this block
   WFrags wf;
   load_w_frags(whh, dir, unit0, n, kbase, wf);
-  // cell owner: thread tid -> utterance tid >> 4, unit tid & 15 (32 x 16 = 512 = one cell per thread)
+  // cell owner: thread tid -> utterance tid >> 4, unit tid & 15 (32 x 16 = 512 = one cell per thread; rows >= B publish zeros)
   const int cb = tid >> 4, cu = tid & 15;
   const bool own = cb < B;
   const int my_off = own ? off[cb] : 0, my_len = own ? len[cb] : 0;
   float c_state = 0.f, h_state = 0.f;
-  float* const hdir = hx + (size_t)dir * 2 * kMaxB * kH;
+  float* const hdir = hx + (size_t)dir * kRing * kMaxB * kH;
+  const size_t cell = (size_t)cb * kH + unit0 + cu;
   const bool two_tiles = B > 16;
+  bool dead = false;                                       // the exchange timed out (here or in another block): stop waiting
 
-  // gate pre-activations of the input projection for step t are fetched during step t-1 (HBM latency off the chain)
-  float gpre[4] = {0.f, 0.f, 0.f, 0.f};
-  int frame = 0;
-  bool live = false;
-  auto fetch_gx = [&](int t) {
-    live = t < my_len;
-    frame = live ? my_off + (dir == 0 ? t : my_len - 1 - t) : 0;
-    const float* gp = gx + (size_t)frame * (8 * kH) + (size_t)dir * 4 * kH + unit0 + cu;
+  // gate pre-activations of the input projection: those of step t + 1 are requested right after the poll of step t, a whole
+  // step before the next `s_waitcnt vmcnt(0)` (HBM latency off the chain)
+  auto gx_ptr = [&](int t, bool& live_t, int& frame_t) {
+    live_t = t < my_len;
+    frame_t = live_t ? my_off + (dir == 0 ? t : my_len - 1 - t) : 0;
+    return gx + (size_t)frame_t * (8 * kH) + (size_t)dir * 4 * kH + unit0 + cu;
+  };
+  float gpre[4], gnext[4] = {0.f, 0.f, 0.f, 0.f};
+  bool live, live_n = false;
+  int frame, frame_n = 0;
+  {
+    const float* gp = gx_ptr(0, live, frame);
 #pragma unroll
     for (int g = 0; g < 4; ++g) gpre[g] = live ? gp[g * kH] : 0.f;
-  };
-  fetch_gx(0);
+  }
 
   for (int t = 0; t < Lmax; ++t) {
-    const float* hprev = hdir + (size_t)(t & 1) * kMaxB * kH;
-    float* hnext = hdir + (size_t)((t & 1) ^ 1) * kMaxB * kH;
-    // previous h of utterance rows n and n + 16
+    const float* hprev = hdir + (size_t)(t & 3) * kMaxB * kH;
+    float* hnext = hdir + (size_t)((t + 1) & 3) * kMaxB * kH;
+    float* hreset = hdir + (size_t)((t + 3) & 3) * kMaxB * kH;
+    // previous h of utterance rows n and n + 16: polled until every value has arrived
     f32x4 ha[kKL / 4], hb[kKL / 4];
     {
       const float* a0 = hprev + (size_t)n * kH + kbase;
-      if (two_tiles) {
-        load32_l2(a0, a0 + 16 * kH, ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]);
-      } else {
-        load16_l2(a0, ha[0], ha[1], ha[2], ha[3]);
+      unsigned spins = 0;
+      for (;;) {
+        float m;
+        if (two_tiles) {
+          load32_l2(a0, a0 + 16 * kH, ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]);
+          m = fmaxf(fmaxf(fmaxf(max4(ha[0]), max4(ha[1])), fmaxf(max4(ha[2]), max4(ha[3]))),
+                    fmaxf(fmaxf(max4(hb[0]), max4(hb[1])), fmaxf(max4(hb[2]), max4(hb[3]))));
+        } else {
+          load16_l2(a0, ha[0], ha[1], ha[2], ha[3]);
+          m = fmaxf(fmaxf(max4(ha[0]), max4(ha[1])), fmaxf(max4(ha[2]), max4(ha[3])));
+        }
+        if (m <= 1.5f || dead) break;
+        if ((++spins & 31u) == 0u) {                       // a lost block must not hang the GPU: flag it, tell the others, go on
+          if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
+          if (spins > kSpinLimit) { bar[2] = 1u; dead = true; break; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!two_tiles) {
 #pragma unroll
         for (int s4 = 0; s4 < kKL / 4; ++s4) hb[s4] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    hreset[cell] = __builtin_bit_cast(float, kSentinelBits);
+    if (t + 1 < Lmax) {
+      const float* gp = gx_ptr(t + 1, live_n, frame_n);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gnext[g] = live_n ? gp[g * kH] : 0.f;
+    }
+    // every block of a direction must sit on the same XCD, or the exchange above is not coherent (block 0's note was acknowledged
+    // before it published h(0), which this block has just seen)
+    if (t == 1 && tid == 0 && __hip_atomic_load(&bar[4 + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc + 1u) bar[2] = 2u;
     f32x4 acc[2][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -210,39 +259,25 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
         red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r] * kWScaleInv;
       }
     __syncthreads();
-    if (own) {
-      if (live) {
-        float pre[4];
+    if (live) {
+      float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = (g ^ ((cb >> 2) & 3)) * kUnits + cu;
-          float a = gpre[g];
+      for (int g = 0; g < 4; ++g) {
+        const int col = (g ^ ((cb >> 2) & 3)) * kUnits + cu;
+        float a = gpre[g];
 #pragma unroll
-          for (int w = 0; w < kWaves; ++w) a += red[w][cb][col];
-          pre[g] = a;
-        }
-        c_state = sigmoidf_(pre[1]) * c_state + sigmoidf_(pre[0]) * tanhf(pre[2]);
-        h_state = sigmoidf_(pre[3]) * tanhf(c_state);
-        y[(size_t)frame * (2 * kH) + (size_t)dir * kH + unit0 + cu] = h_state;
+        for (int w = 0; w < kWaves; ++w) a += red[w][cb][col];
+        pre[g] = a;
       }
-      hnext[(size_t)cb * kH + unit0 + cu] = h_state;        // finished utterances keep publishing their last h (unused)
+      c_state = sigmoidf_(pre[1]) * c_state + sigmoidf_(pre[0]) * tanhf(pre[2]);
+      h_state = sigmoidf_(pre[3]) * tanhf(c_state);
+      y[(size_t)frame * (2 * kH) + (size_t)dir * kH + unit0 + cu] = h_state;
     }
-    // step barrier among the 32 blocks of this direction: stores acknowledged by the L2, count in, spin (bounded)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t + 1 < Lmax) fetch_gx(t + 1);                       // in flight across the barrier
-    __syncthreads();
-    if (tid == 0) {
-      atomicAdd(&bar[dir], 1u);
-      const unsigned want = (unsigned)kBlocksPerDir * (unsigned)(t + 1);
-      unsigned spins = 0;
-      while (__hip_atomic_load(&bar[dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (++spins > (1u << 22)) { bar[2] = 1u; break; }      // a lost block must not hang the GPU: flag it and go on
-        __builtin_amdgcn_s_sleep(1);
-      }
-      // every block of a direction must sit on the same XCD, or the exchange above is not coherent
-      if (t == 0 && __hip_atomic_load(&bar[4 + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc + 1u) bar[2] = 2u;
-    }
-    __syncthreads();
+    hnext[cell] = h_state;        // every cell, every step: finished utterances republish their last h, rows >= B a zero (unused)
+    __syncthreads();              // `red` is rewritten by the next step
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gpre[g] = gnext[g];
+    live = live_n; frame = frame_n;
   }
 }
 
@@ -379,12 +414,16 @@ hipError_t launch_blstm(const float* gx, const float* whh, float* y, float* hx, 
                         hipStream_t s) {
   if (B <= 0 || Lmax <= 0) return hipSuccess;
   if (B > kMaxB) return hipErrorInvalidValue;
-  // hx: exchange buffer, then kBarWords words of barrier state; the error flag (word 2) survives across launches
-  hipError_t e = hipMemsetAsync(hx, 0, (size_t)2 * 2 * kMaxB * kH * sizeof(float) + 2 * sizeof(unsigned), s);
+  // hx: the exchange ring of both directions (buffer 0 = h_0 = zeros, the others the sentinel), then 8 words of state; the error
+  // flag (word 2) survives across launches
+  const size_t buf = (size_t)kMaxB * kH;
+  hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hx), (int)kSentinelBits, 2 * kRing * buf, s);
   if (e != hipSuccess) return e;
-  unsigned* bar = reinterpret_cast<unsigned*>(hx + (size_t)2 * 2 * kMaxB * kH);
-  e = hipMemsetAsync(bar, 0, 2 * sizeof(unsigned), s);
-  if (e != hipSuccess) return e;
+  for (int d = 0; d < 2; ++d) {
+    e = hipMemsetAsync(hx + (size_t)d * kRing * buf, 0, buf * sizeof(float), s);
+    if (e != hipSuccess) return e;
+  }
+  unsigned* bar = reinterpret_cast<unsigned*>(hx + 2 * kRing * buf);
   // one block per (XCD, slot): blocks 8 i + d land on XCD d; only d = 0, 1 work, the rest return at once
   hipLaunchKernelGGL(blstm_kernel, dim3(kXcds * kBlocksPerDir), dim3(kBlstmThreads), 0, s, gx, whh, y, hx, bar, off, len, B, Lmax);
   return hipGetLastError();

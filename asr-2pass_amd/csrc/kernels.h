@@ -144,8 +144,8 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
 // + biases (forward i,f,g,o | backward i,f,g,o), whh [2][2048][512], y [rows, 1024]; hx = kBlstmScratchFloats floats of
 // scratch, ZEROED ONCE by the caller; its word kBlstmFlagWord is an error flag the kernel sets (1 = step barrier timed
 // out, 2 = the blocks of a direction were not all on one XCD) — check it after the stream has drained.
-constexpr int kBlstmScratchFloats = 2 * 2 * 32 * 512 + 8;
-constexpr int kBlstmFlagWord = 2 * 2 * 32 * 512 + 2;
+constexpr int kBlstmScratchFloats = 2 * 4 * 32 * 512 + 8;      // exchange ring [2 dir][4][32][512], then 8 state words
+constexpr int kBlstmFlagWord = 2 * 4 * 32 * 512 + 2;
 hipError_t launch_blstm(const float* gx, const float* whh, float* y, float* hx, const int* off, const int* len, int B, int Lmax,
                         hipStream_t s);
 // The same recurrence as one launch per time step (no inter-block exchange inside a launch: works whatever else runs on the

@@ -29,6 +29,15 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using float2v = __attribute__((ext_vector_type(2))) float;
 
+// Timing-only builds (tools/x3_variant.sh <name> "-DPFHIP_ATT_ABLATE=n" attention_x3.hip; results are WRONG for n != 0):
+//   1 no FSMN prologue   2 no tile barrier   3 no softmax arithmetic   4 V fragments of one address only   5 no staging of the next tile
+//   6 = 2 + 3 + 4 + 5 (MFMAs and K-fragment reads only)
+#ifndef PFHIP_ATT_ABLATE
+#define PFHIP_ATT_ABLATE 0
+#endif
+constexpr bool kAbNoFsmn = PFHIP_ATT_ABLATE == 1, kAbNoBar = PFHIP_ATT_ABLATE == 2 || PFHIP_ATT_ABLATE == 6,
+               kAbNoSoftmax = PFHIP_ATT_ABLATE == 3 || PFHIP_ATT_ABLATE == 6, kAbOneV = PFHIP_ATT_ABLATE == 4 || PFHIP_ATT_ABLATE == 6,
+               kAbNoStage = PFHIP_ATT_ABLATE == 5 || PFHIP_ATT_ABLATE == 6;
 constexpr int kHD = 128, kQW = 32, kNW = 8, kQB = kNW * kQW, kKT = 32;   // 8 waves = 256 queries per workgroup, two waves per SIMD
 constexpr int kKRow = 272;                       // bytes per key row of a K plane (128 bf16 + 16 pad: conflict-free b128 reads)
 constexpr int kKPlane = kKT * kKRow;             // 8,704
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
   // encoder layer less.  With mem_accumulate the memory is added straight into the residual stream (mem = x): the output
   // projection that follows — bandwidth-bound at N = K = 512: 128 MB of operand, two residuals and result per 8.4 GFLOP — then
   // reads one residual instead of two; the 33 MB move into this kernel, which has bandwidth to spare.
-  if (fsmn_w) {
+  if (fsmn_w && !kAbNoFsmn) {
     constexpr int kTaps = 11, kStrip = 16;
     const int cg = tid & 31, strip = tid >> 5;
     const int c = head * kHD + 4 * cg, t0 = q0 + strip * kStrip;
@@ -221,9 +230,9 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
 #define PFHIP_MM(a_, b_) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, sacc, 0, 0, 0)
     // one stage of the next tile's split: HI writes the high plane of four values and keeps their residuals, LO writes the low plane
 #define PFHIP_HI(a_, c_, e_, g_, dst)                                                                     \
-  { th0 = hi_pair(a_, c_); th1 = hi_pair(e_, g_); *reinterpret_cast<uint2*>(dst) = make_uint2(th0, th1);  \
+  if (!kAbNoStage) { th0 = hi_pair(a_, c_); th1 = hi_pair(e_, g_); *reinterpret_cast<uint2*>(dst) = make_uint2(th0, th1);  \
     t0 = sub_lo(a_, th0); t1 = sub_hi(c_, th0); t2 = sub_lo(e_, th1); t3 = sub_hi(g_, th1); }
-#define PFHIP_LO(dst) { *reinterpret_cast<uint2*>(dst) = make_uint2(lo_pair(t0, t1), lo_pair(t2, t3)); }
+#define PFHIP_LO(dst) if (!kAbNoStage) { *reinterpret_cast<uint2*>(dst) = make_uint2(lo_pair(t0, t1), lo_pair(t2, t3)); }
     half8 k0, k1, n0, n1;
     PFHIP_KF(k0, 0, 0); PFHIP_KF(k1, 1, 0);
     PFHIP_SB;
@@ -272,12 +281,14 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
 #undef PFHIP_KF
 #undef PFHIP_SB
     __builtin_amdgcn_sched_barrier(0);
-    load_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);      // past the end: re-fetch the last tile (never used)
+    if (!kAbNoStage) load_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);      // past the end: re-fetch the last tile (never used)
     __builtin_amdgcn_sched_barrier(0);
 
     // online softmax (base 2) for query column r; this lane holds keys (e&3) + 8*(e>>2) + 4*h of the tile
     float tmax = -INFINITY;
-    if ((kt + 1) * kKT <= Lk) {
+    if (kAbNoSoftmax) {
+      tmax = m_run;
+    } else if ((kt + 1) * kKT <= Lk) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
     } else {
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(sacc[e] - m_run);
+      const float pv = kAbNoSoftmax ? sacc[e] : __builtin_amdgcn_exp2f(sacc[e] - m_run);
       sacc[e] = pv;
       psum += pv;
     }
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
       split8(pv, p0, p1);
 #define PFHIP_PV(OACC, dt)                                                                                        \
       {                                                                                                           \
-        const unsigned char* vp = vb + (dt) * 32 * kVRow + 32 * t;                                                \
+        const unsigned char* vp = kAbOneV ? vb : vb + (dt) * 32 * kVRow + 32 * t;                                 \
         half8 v0, v1;                                                                                             \
         {                                                                                                         \
           const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 16);    \
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
       PFHIP_PV(oacc0, 0) PFHIP_PV(oacc1, 1) PFHIP_PV(oacc2, 2) PFHIP_PV(oacc3, 3)
 #undef PFHIP_PV
     }
-    __syncthreads();
+    if (!kAbNoBar) __syncthreads();
   }
 
   // ---- normalise, transpose through LDS, store full rows (as attention.hip) ---------------------------------------------

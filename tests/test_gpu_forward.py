@@ -51,6 +51,24 @@ def test_feats_ragged_batch_and_edges(small):
             assert np.abs(g_ - ref).max() < FEAT_TOL
 
 
+def test_feats_more_than_64_utterances(small):
+    """The kernel finds a frame's utterance by ballots over the frame-offset table, 64 entries at a time: 150 utterances (three
+    table chunks), odd sample counts (unaligned utterance starts), empty and too-short ones in between."""
+    model, W = small
+    rng = np.random.default_rng(7)
+    lens = [int(v) for v in rng.integers(300, 4001, size=150)]
+    for i in (0, 63, 64, 65, 127, 128, 149):
+        lens[i] = [0, 399, 401, 1361, 0, 977, 2001][(i * 7) % 7]
+    utts = [synth_pcm(i, n, rng) for i, n in enumerate(lens)]
+    got = model.extract_feats(utts)
+    assert len(got) == len(utts)
+    for u, g_ in zip(utts, got):
+        ref = fe.extract_feats(u, W["cmvn.mean"], W["cmvn.istd"])
+        assert g_.shape == ref.shape
+        if ref.size:
+            assert np.abs(g_ - ref).max() < FEAT_TOL
+
+
 def test_forward_ragged_batch_matches_oracle(small):
     """Mixed lengths incl. an utterance too short for one window; per-stage + token-for-token."""
     model, W = small

@@ -78,7 +78,7 @@ std::string HostVocab::Vector2StringV2(const std::vector<int>& in, const std::st
     return out;
   }
 
-  const bool space_after_chinese = last_is_complete_english_;       // what the previous call left behind (:176)
+  const bool space_after_chinese = last_is_complete_english_.load(std::memory_order_relaxed);       // what the previous call left behind (:176)
   bool prev_latin = false;
   size_t prev_latin_len = 0;
   // a finished word: Chinese characters are appended bare; a Latin word gets a space in front when it follows a Latin word
@@ -107,7 +107,7 @@ std::string HostVocab::Vector2StringV2(const std::vector<int>& in, const std::st
     }
     if (gluing) { w = glued + w; glued.clear(); gluing = false; }
     put(w);
-    last_is_complete_english_ = i + 1 == n && !IsChinese(w) && !piece;           // (:283-288)
+    last_is_complete_english_.store(i + 1 == n && !IsChinese(w) && !piece, std::memory_order_relaxed);           // (:283-288)
   }
   return out;
 }

@@ -13,6 +13,7 @@
 //   * a "xx@@" piece in front of a Chinese character is closed with a trailing space (:205-214);
 //   * the last two bytes of a piece that CONTAINS "@@" are dropped wherever the marker sits (:206, :216, :226).
 #pragma once
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -35,7 +36,8 @@ class HostVocab {
 
  private:
   std::vector<std::string> vocab_;
-  bool last_is_complete_english_ = false;
+  // carried from call to call as in the reference (vocab.cpp:176); atomic because the decoder threads share the vocabulary
+  std::atomic<bool> last_is_complete_english_{false};
 };
 
 }  // namespace pfhip_host

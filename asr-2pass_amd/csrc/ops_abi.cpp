@@ -81,14 +81,20 @@ float pfhip_op_best_w_scale(float max_abs) { return pfhip::best_w_scale(max_abs)
 
 size_t pfhip_op_plane_image_bytes(int rows, int K) { return pfhip::plane_image_bytes(rows, K); }
 int pfhip_op_split_planes(const float* X, int ld, int rows_valid, int rows, int K, float scale, void* hi, void* lo, void* stream) {
-  if (K % 16 || rows % 128 || rows_valid > rows) return (int)hipErrorInvalidValue;
+  if (K < 16 || K % 16 || rows <= 0 || rows % 128 || rows_valid < 0 || rows_valid > rows || !hi || !lo || (rows_valid > 0 && (!X || ld < K)))
+    return (int)hipErrorInvalidValue;
   pfhip::launch_split_planes(X, ld, rows_valid, rows, K, scale, hi, lo, S(stream));
   return (int)hipGetLastError();
 }
 int pfhip_op_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                      void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, int relu,
                      const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, void* stream) {
-  if (K % 16 || N % 128 || rows_a % 128 || rows_w % 128 || (!C && !Ph) || !(w_scale > 0.f)) return (int)hipErrorInvalidValue;
+  // everything the kernel and its grid assume, checked here: a wrong image size would be an out-of-bounds DMA on the device
+  const int mp = (M + 127) / 128 * 128;
+  if (M <= 0 || N <= 0 || K < 16 || K % 16 || N % 128 || rows_a % 128 || rows_w % 128 || rows_a < mp || rows_w < N || !Ah || !Al || !Wh ||
+      !Wl || (!C && !Ph) || (Ph && (!Pl || rows_p % 128 || rows_p < mp)) || (C && ldc < N) || (R1 && ldr1 < N) || !(w_scale > 0.f) ||
+      (ln_stats && (!ln_colsum || ln_tiles <= 0)))
+    return (int)hipErrorInvalidValue;
   pfhip::launch_gemm_p3(Ah, Al, rows_a, Wh, Wl, rows_w, w_scale, C, ldc, Ph, Pl, rows_p, bias, R1, ldr1, M, N, K, relu != 0, ln_stats, ln_tiles,
                         ln_colsum, stats_out, 4, S(stream));
   return (int)hipGetLastError();

@@ -380,6 +380,23 @@ def test_gemm_on_pre_split_operands(ops, M, N, K, relu):
         assert np.abs(C3.cpu().numpy()[:M] - ref2 @ W2.astype(np.float64).T).max() < 2 * tol * max(1.0, np.sqrt(N / 512)) * max(1.0, np.abs(ref2).max() / 4)
 
 
+def test_gemm_on_pre_split_operands_refuses_bad_shapes(ops):
+    """The operator checks on the host what its grid and DMA assume; a refused call launches nothing."""
+    A = dev(np.ones((128, 64), np.float32))
+    W = dev(np.ones((128, 64), np.float32))
+    a_img, w_img = ops.split_planes(A), ops.split_planes(W)
+    for kw in (dict(M=129, N=128, K=64),       # more rows than the A image holds
+               dict(M=128, N=256, K=64),       # more columns than the W image holds
+               dict(M=128, N=128, K=72),       # K not a multiple of the 16-deep step
+               dict(M=128, N=96, K=64)):       # N not a multiple of the tile
+        with pytest.raises(RuntimeError):
+            ops.gemm_p3(a_img, w_img, kw["M"], kw["N"], kw["K"])
+    with pytest.raises(RuntimeError):
+        ops.gemm_p3(a_img, w_img, 128, 128, 64, w_scale=0.0)
+    C, _ = ops.gemm_p3(a_img, w_img, 128, 128, 64)
+    assert np.array_equal(C.cpu().numpy(), np.full((128, 128), 64.0, np.float32))
+
+
 def test_gemm_bf16_split_stated_domain(ops):
     """Where the three-plane split (gemm_x6.hip: rest(x) = x - top16(x)) stops being an fp32 GEMM, pinned:
       * a non-finite operand: Inf - Inf = NaN in the second plane, so EVERY output of that row is NaN (an fp32 GEMM would carry

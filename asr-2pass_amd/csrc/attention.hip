@@ -292,12 +292,15 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
 
 // the split-operand attention: two fp16 planes / three products (attention_x3.hip, default) or three bf16 planes / six products
 // (attention_x6.hip, PFHIP_ATT_X3=0)
+static bool att_x3_on() {
+  static const bool x3 = [] { const char* e = getenv("PFHIP_ATT_X3"); return !(e && e[0] == '0'); }();
+  return x3;
+}
 static void launch_attention_split(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                                    const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
                                    float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0,
-                                   bool mem_accumulate = false) {
-  static const bool x3 = [] { const char* e = getenv("PFHIP_ATT_X3"); return !(e && e[0] == '0'); }();
-  if (x3) launch_attention_x3(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
+                                   bool mem_accumulate = false, void* planes_hi = nullptr, void* planes_lo = nullptr, int plane_rows = 0) {
+  if (att_x3_on()) launch_attention_x3(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate, planes_hi, planes_lo, plane_rows);
   else launch_attention_x6(Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
 }
 
@@ -311,12 +314,15 @@ bool attention_fsmn_is_fused(int max_len) {
   return fuse && att_x6_on() && max_len > 64;
 }
 
+bool attention_planes_ok(int max_len) { return attention_fsmn_is_fused(max_len) && att_x3_on(); }
+
 void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                            const int* off, const int* len, int B, int H, int max_len, float scale, const float* fsmn_w, float* mem,
-                           int ldmem, hipStream_t s, bool mem_accumulate) {
+                           int ldmem, hipStream_t s, bool mem_accumulate, void* planes_hi, void* planes_lo, int plane_rows) {
   if (B <= 0 || max_len <= 0) return;
   if (attention_fsmn_is_fused(max_len)) {
-    launch_attention_split(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate);
+    launch_attention_split(Q, ldq, K, ldk, V, ldv, O, ldo, off, len, off, len, B, H, max_len, scale, s, fsmn_w, mem, ldmem, mem_accumulate,
+                           planes_hi, planes_lo, plane_rows);
     return;
   }
   launch_fsmn(V, ldv, fsmn_w, nullptr, 0, mem, ldmem, off, len, B, max_len, H * kHeadDim, s);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
     const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
     float* __restrict__ O, int ldo, const int* __restrict__ q_off, const int* __restrict__ q_len,
     const int* __restrict__ kv_off, const int* __restrict__ kv_len, float scale, const float* __restrict__ fsmn_w,
-    float* mem, int ldmem, int mem_accumulate) {
+    float* mem, int ldmem, int mem_accumulate, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl, int rows_p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int b = blockIdx.y, head = blockIdx.x;
@@ -365,7 +365,26 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
   PFHIP_O_STORE(oacc0, 0) PFHIP_O_STORE(oacc1, 1) PFHIP_O_STORE(oacc2, 2) PFHIP_O_STORE(oacc3, 3)
 #undef PFHIP_O_STORE
   __syncthreads();
-  {
+  if (Ph) {
+    // The context as the two fp16 plane images the output projection stages by LDS-DMA (gemm_p3.hip: [K / 16][rows][16] per plane,
+    // the 16-byte halves of a row swapped where row bit 3 is set): lane = (query row, 8-column piece), so one store instruction of a
+    // wave covers 32 rows x 32 bytes = 1 KB of an image, contiguous.
+    const int pc = h, qrow = q0 + wave * kQW + r;
+    const size_t grow = qbase + (size_t)qrow;
+    if (qrow < Lq) {
+#pragma unroll
+      for (int ks = 0; ks < kHD / 16; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(os + r * kOS + 16 * ks + 8 * pc);
+        const float4 c = *reinterpret_cast<const float4*>(os + r * kOS + 16 * ks + 8 * pc + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        half8 p0, p1;
+        split8(v, p0, p1);
+        const size_t off = ((size_t)(head * (kHD / 16) + ks) * rows_p + grow) * 32 + (size_t)((pc ^ (int)((grow >> 3) & 1)) << 4);
+        *reinterpret_cast<uint4*>(Ph + off) = __builtin_bit_cast(uint4, p0);
+        *reinterpret_cast<uint4*>(Pl + off) = __builtin_bit_cast(uint4, p1);
+      }
+    }
+  } else {
     constexpr int C4 = kHD / 4, RW = 64 / C4;
 #pragma unroll
     for (int pass = 0; pass < kQW / RW; ++pass) {
@@ -383,7 +402,8 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(
 
 void launch_attention_x3(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
-                         float scale, hipStream_t s, const float* fsmn_w, float* mem, int ldmem, bool mem_accumulate) {
+                         float scale, hipStream_t s, const float* fsmn_w, float* mem, int ldmem, bool mem_accumulate, void* planes_hi,
+                         void* planes_lo, int plane_rows) {
   if (B <= 0 || max_q_len <= 0) return;
   static std::atomic<unsigned long long> attr_done{0};      // > 64 KB of dynamic LDS needs the opt-in once per device
   int dev = 0;
@@ -395,7 +415,8 @@ void launch_attention_x3(const float* Q, int ldq, const float* K, int ldk, const
   }
   const dim3 grid(H, B, (max_q_len + kQB - 1) / kQB), block(512);
   hipLaunchKernelGGL(attention_x3_kernel, grid, block, kLdsBytes, s, Q, ldq, K, ldk, V, ldv, O, ldo, q_off, q_len, kv_off,
-                     kv_len, scale, fsmn_w, mem, ldmem, mem_accumulate ? 1 : 0);
+                     kv_len, scale, fsmn_w, mem, ldmem, mem_accumulate ? 1 : 0, static_cast<unsigned char*>(planes_hi),
+                     static_cast<unsigned char*>(planes_lo), plane_rows);
 }
 
 }  // namespace pfhip

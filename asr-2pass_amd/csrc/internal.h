@@ -134,6 +134,11 @@ struct pfhip_model {
   // bias + W beta, for qkv (layers >= 1) and ffn1; [layers][N][d] / [layers][N]
   float* d_lnw_qkv = nullptr; float* d_lnb_qkv = nullptr; float* d_lnw_ffn1 = nullptr; float* d_lnb_ffn1 = nullptr;
   float* d_lns_qkv = nullptr; float* d_lns_ffn1 = nullptr;      // column sums of the folded weights [layers][N]
+  // fp16 plane images (gemm_p3.hip) of the encoder's four large weights per layer, scale baked in: [layer] { qkv' | out | ffn1' |
+  // ffn2 }, each image hi plane then lo plane.  wp_layer_bytes = 0: not built (the fp32 path serves every batch size).
+  unsigned char* d_wplanes = nullptr;
+  size_t wp_layer_bytes = 0, wp_off_out = 0, wp_off_ffn1 = 0, wp_off_ffn2 = 0;
+  Buf ctxP, xP, hP;                                             // activation plane images of a large batch: context, residual stream, FFN hidden
   // the same for the decoder's FFN: ffn1 with norm1, ffn2 with ffn_norm; [dec_layers + 1] entries (the last one is dec3)
   float* d_dlnw1 = nullptr; float* d_dlnb1 = nullptr; float* d_dlns1 = nullptr;
   float* d_dlnw2 = nullptr; float* d_dlnb2 = nullptr; float* d_dlns2 = nullptr;

@@ -126,12 +126,16 @@ void launch_attention_x6(const float* Q, int ldq, const float* K, int ldk, const
 void launch_attention_x3(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                          const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,
                          float scale, hipStream_t s, const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0,
-                         bool mem_accumulate = false);
+                         bool mem_accumulate = false, void* planes_hi = nullptr, void* planes_lo = nullptr, int plane_rows = 0);
 // Encoder-layer pair: FSMN memory of V (into mem) + self-attention (into O).  One launch where the BF16 attention kernel runs
 // (d_k = 128, more than 64 queries per utterance), otherwise launch_fsmn + launch_attention.  C = V's channel count (H * 128).
 void launch_attention_fsmn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                            const int* off, const int* len, int B, int H, int max_len, float scale, const float* fsmn_w, float* mem,
-                           int ldmem, hipStream_t s, bool mem_accumulate = false);
+                           int ldmem, hipStream_t s, bool mem_accumulate = false, void* planes_hi = nullptr, void* planes_lo = nullptr,
+                           int plane_rows = 0);
+// whether launch_attention_fsmn can write the context as fp16 plane images (gemm_p3.hip's A operand) instead of fp32 rows: the
+// fused launch on attention_x3.hip only.  With planes_hi set, O is not written.
+bool attention_planes_ok(int max_len);
 // whether launch_attention_fsmn will be the single fused launch (then, and only then, mem_accumulate is honoured: the caller may
 // pass the residual stream as `mem` and drop the memory term from the output projection)
 bool attention_fsmn_is_fused(int max_len);

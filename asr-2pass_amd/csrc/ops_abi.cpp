@@ -126,6 +126,15 @@ int pfhip_op_attention_hd(const float* Q, int ldq, const float* K, int ldk, cons
                              S(stream));
   return done();
 }
+int pfhip_op_attention_planes(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* planes_hi, void* planes_lo,
+                              int plane_rows, const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                              int max_q_len, int total_q_rows, float scale, void* stream) {
+  // the image must hold every query row the launch writes (rows are global: q_off[b] + t), in whole 128-row tiles
+  if (!planes_hi || !planes_lo || plane_rows % 128 || total_q_rows > plane_rows || B <= 0 || H <= 0) return (int)hipErrorInvalidValue;
+  pfhip::launch_attention_x3(Q, ldq, K, ldk, V, ldv, nullptr, 0, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, S(stream), nullptr,
+                             nullptr, 0, false, planes_hi, planes_lo, plane_rows);
+  return done();
+}
 int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
                  float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream) {
   if (D > 1024) return (int)hipErrorInvalidValue;

@@ -298,6 +298,32 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
         reg_scale(m->d_lnw_qkv + (size_t)i * 3 * d * d, &wq[(size_t)i * 3 * d * d], (size_t)3 * d * d);
         reg_scale(m->d_lnw_ffn1 + (size_t)i * c.ffn * d, &wf[(size_t)i * c.ffn * d], (size_t)c.ffn * d);
       }
+      // The same four weights of every layer once more as fp16 plane images, pre-multiplied by their scale (gemm_p3.hip): on large
+      // batches the encoder's GEMMs stage both operands by LDS-DMA — the activations arrive as plane images from the kernel that
+      // produced them (enqueue_locked).  Same bytes as the fp32 copies (0.6 GB for Paraformer-large); PFHIP_PLANES=0 skips them.
+      static const bool planes_on = [] { const char* e = getenv("PFHIP_PLANES"); return !(e && e[0] == '0'); }();
+      if (planes_on && c.ffn % pfhip::kTileN == 0) {
+        const size_t iq = 2 * pfhip::plane_image_bytes(3 * d, d), io = 2 * pfhip::plane_image_bytes(d, d);
+        const size_t i1 = 2 * pfhip::plane_image_bytes(c.ffn, d), i2 = 2 * pfhip::plane_image_bytes(d, c.ffn);
+        m->wp_off_out = iq; m->wp_off_ffn1 = iq + io; m->wp_off_ffn2 = iq + io + i1;
+        const size_t per_layer = iq + io + i1 + i2;
+        HIP_TRY(hipMalloc((void**)&m->d_wplanes, per_layer * (size_t)L));
+        for (int i = 0; i < L; ++i) {
+          const std::string ep = "enc." + std::to_string(i) + ".";
+          unsigned char* base = m->d_wplanes + per_layer * (size_t)i;
+          const float* wqkv = m->d_lnw_qkv + (size_t)i * 3 * d * d;
+          const float* wff1 = m->d_lnw_ffn1 + (size_t)i * c.ffn * d;
+          const float* wout = m->W(ep + "out.w").d;
+          const float* wff2 = m->W(ep + "ffn2.w").d;
+          if (i > 0) pfhip::launch_split_planes(wqkv, d, 3 * d, 3 * d, d, m->w_scale_of(wqkv), base, base + iq / 2, nullptr);
+          pfhip::launch_split_planes(wout, d, d, d, d, m->w_scale_of(wout), base + m->wp_off_out, base + m->wp_off_out + io / 2, nullptr);
+          pfhip::launch_split_planes(wff1, d, c.ffn, c.ffn, d, m->w_scale_of(wff1), base + m->wp_off_ffn1, base + m->wp_off_ffn1 + i1 / 2, nullptr);
+          pfhip::launch_split_planes(wff2, c.ffn, d, d, c.ffn, m->w_scale_of(wff2), base + m->wp_off_ffn2, base + m->wp_off_ffn2 + i2 / 2, nullptr);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        m->wp_layer_bytes = per_layer;
+      }
       if (!st && c.dec_ffn % pfhip::kTileN == 0) {          // decoder FFNs: layers 0..dec_layers-1 and dec3 (the last entry)
         const int DL = c.dec_layers + 1, f = c.dec_ffn;
         std::vector<float> w1((size_t)DL * f * d + (size_t)pfhip::kTileN * d, 0.f), b1((size_t)DL * f + pfhip::kTileN, 0.f), s1(b1.size(), 0.f);
@@ -404,7 +430,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   X(d_blob) X(d_w0qkv) X(d_predconv) X(d_vocab_bias) X(d_kv_all_w) X(d_kv_all_b) X(d_lnw_qkv) X(d_lnb_qkv) X(d_lnw_ffn1)     \
   X(d_lnb_ffn1) X(d_lns_qkv) X(d_lns_ffn1) X(d_dlnw1) X(d_dlnb1) X(d_dlns1) X(d_dlnw2) X(d_dlnb2) X(d_dlns2) X(d_dlnw3)        \
   X(d_dlnb3) X(d_dlns3) X(d_up_w) X(d_up_b) X(d_wih) X(d_bih) X(d_whh) X(d_window) X(d_tw) X(d_mel_off) X(d_mel_size)         \
-  X(d_mel_w) X(d_inv_ts)
+  X(d_mel_w) X(d_inv_ts) X(d_wplanes)
 
 pfhip_status create_streams(pfhip_model* m) {
   HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
@@ -427,6 +453,8 @@ pfhip_status build_context(pfhip_model* owner, pfhip_model** out) {
   m->t = owner->t;
   m->wscale = owner->wscale;
   m->out2_b = owner->out2_b;
+  m->wp_layer_bytes = owner->wp_layer_bytes; m->wp_off_out = owner->wp_off_out; m->wp_off_ffn1 = owner->wp_off_ffn1;
+  m->wp_off_ffn2 = owner->wp_off_ffn2;
 #define X(f) m->f = owner->f;
   PFHIP_WEIGHT_PTRS(X)
 #undef X
@@ -552,12 +580,54 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     pfhip::launch_gemm_f32_x6_ln(A, K, Wd, K, Cd, ldc, bias, R1, d, R2, d, M, N, K, relu, ln_colsum ? m->lnstats.f() : nullptr, 4,
                                  ln_colsum, stats_out ? m->lnstats.f() : nullptr, s, m->w_scale_of(Wd));
   };
+  // Large batches, second step: the four big GEMMs of a layer take BOTH operands as fp16 plane images staged by LDS-DMA
+  // (gemm_p3.hip) — weights split once at load, activations written as planes by the kernel that produces them (the attention's
+  // context, the residual stream out of the output projection and FFN2, FFN1's hidden activation).  The fp32 residual stream and
+  // the QKV rows stay fp32 (residual adds, the attention's own staging).  Same arithmetic as the in-loop split of gemm_x3.hip.
+  struct Img { unsigned char* hi; unsigned char* lo; };
+  Img ctxP{nullptr, nullptr}, xP{nullptr, nullptr}, hP{nullptr, nullptr};
+  // gemm_p3.hip has the 128 x 128 tile only: below ~256 tiles for the N = 512 launches (8192 rows) the 64-row tiles of the fp32-operand
+  // kernels fill the chip better (PFHIP_PLANES_MIN_ROWS moves the switch, PFHIP_PLANES=0 at load removes the path)
+  static const int planes_min_rows = [] { const char* e = getenv("PFHIP_PLANES_MIN_ROWS"); return e && *e ? atoi(e) : 8192; }();
+  const bool planes = fuse_ln && mem_in_x && m->wp_layer_bytes != 0 && M >= planes_min_rows && pfhip::attention_planes_ok(m->maxT);
+  if (planes) {
+    const size_t pd = pfhip::plane_image_bytes(Mp, d), pf = pfhip::plane_image_bytes(Mp, c.ffn);
+    HIP_TRY(m->ctxP.ensure(2 * pd));
+    HIP_TRY(m->xP.ensure(2 * pd));
+    HIP_TRY(m->hP.ensure(2 * pf));
+    ctxP = {static_cast<unsigned char*>(m->ctxP.p), static_cast<unsigned char*>(m->ctxP.p) + pd};
+    xP = {static_cast<unsigned char*>(m->xP.p), static_cast<unsigned char*>(m->xP.p) + pd};
+    hP = {static_cast<unsigned char*>(m->hP.p), static_cast<unsigned char*>(m->hP.p) + pf};
+  }
+  struct WImg { const unsigned char* hi; const unsigned char* lo; float scale; };
+  auto wimg = [&](int layer, int which) -> WImg {          // 0 qkv', 1 out, 2 ffn1', 3 ffn2
+    const unsigned char* base = m->d_wplanes + m->wp_layer_bytes * (size_t)layer;
+    const std::string ep = "enc." + std::to_string(layer) + ".";
+    switch (which) {
+      case 0: return {base, base + pfhip::plane_image_bytes(3 * d, d), m->w_scale_of(m->d_lnw_qkv + (size_t)layer * 3 * d * d)};
+      case 1: return {base + m->wp_off_out, base + m->wp_off_out + pfhip::plane_image_bytes(d, d), m->w_scale_of(m->W(ep + "out.w").d)};
+      case 2: return {base + m->wp_off_ffn1, base + m->wp_off_ffn1 + pfhip::plane_image_bytes(c.ffn, d),
+                      m->w_scale_of(m->d_lnw_ffn1 + (size_t)layer * c.ffn * d)};
+      default: return {base + m->wp_off_ffn2, base + m->wp_off_ffn2 + pfhip::plane_image_bytes(d, c.ffn), m->w_scale_of(m->W(ep + "ffn2.w").d)};
+    }
+  };
+  // C (fp32, may be null) and / or plane images of C; LayerNorm folded in when ln_colsum is given (statistics in lnstats)
+  auto gemm_pl = [&](const Img& A, const WImg& W, int N, int K, float* Cd, int ldc, const Img* P, const float* bias, const float* R1, bool relu,
+                     const float* ln_colsum, bool stats_out) {
+    Scope sc(m, s, K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    pfhip::launch_gemm_p3(A.hi, A.lo, Mp, W.hi, W.lo, N, W.scale, Cd, ldc, P ? P->hi : nullptr, P ? P->lo : nullptr, Mp, bias, R1, d, M, N, K, relu,
+                          ln_colsum ? m->lnstats.f() : nullptr, 4, ln_colsum, stats_out ? m->lnstats.f() : nullptr, 4, s);
+  };
   for (int i = 0; i < c.enc_layers; ++i) {
     const std::string p = "enc." + std::to_string(i) + ".";
     const bool first = i == 0;
     const float* xin = first ? m->x0.f() : x;
     const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
-    if (fuse_ln && !first) {
+    if (planes && !first) {
+      // LayerNorm(x) Wqkv'^T on the plane images of x that the previous layer's FFN2 left
+      gemm_pl(xP, wimg(i, 0), 3 * d, d, m->qkv.f(), 3 * d, nullptr, m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, false,
+              m->d_lns_qkv + (size_t)i * 3 * d, false);
+    } else if (fuse_ln && !first) {
       gemm_ln(x, m->d_lnw_qkv + (size_t)i * 3 * d * d, 3 * d, m->qkv.f(), 3 * d, m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, nullptr, false,
               m->d_lns_qkv + (size_t)i * 3 * d, false, d);
     } else {
@@ -572,7 +642,15 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
       // has no residual), so the bandwidth-bound output projection reads ONE residual
       pfhip::launch_attention_fsmn(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, m->m_row_off,
                                    m->m_len, B, c.n_head, m->maxT, att_scale, m->W(p + "fsmn.w").d, mem_in_x ? x : m->mem.f(), d, s,
-                                   mem_in_x && !first);
+                                   mem_in_x && !first, planes ? ctxP.hi : nullptr, planes ? ctxP.lo : nullptr, Mp);
+    }
+    if (planes) {
+      // x = ctx Wo^T + b + (x + memory): fp32 for the residual stream, plane images for FFN1, row statistics for its LayerNorm
+      gemm_pl(ctxP, wimg(i, 1), d, d, x, d, &xP, m->W(p + "out.b").d, x, false, nullptr, true);
+      gemm_pl(xP, wimg(i, 2), c.ffn, d, nullptr, 0, &hP, m->d_lnb_ffn1 + (size_t)i * c.ffn, nullptr, true, m->d_lns_ffn1 + (size_t)i * c.ffn, false);
+      const bool more = i + 1 < c.enc_layers;
+      gemm_pl(hP, wimg(i, 3), d, c.ffn, x, d, more ? &xP : nullptr, m->W(p + "ffn2.b").d, x, false, nullptr, more);
+      continue;
     }
     // x = (first ? 0 : x) + ctx*Wo + b + fsmn_memory
     if (fuse_ln) {
@@ -1087,7 +1165,7 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst, &m->ctxP, &m->xP, &m->hP})
     b->release();
   if (!m->weights_of) {          // a context borrows these
 #define X(f) if (m->f) (void)hipFree((void*)m->f);

@@ -154,6 +154,23 @@ def attention(Q, K, V, q_off, q_len, kv_off, kv_len, n_head, scale, head_dim=128
     return O
 
 
+def attention_planes(Q, K, V, q_off, q_len, kv_off, kv_len, n_head, scale):
+    """attention (d_k = 128) with the context as fp16 plane images: returns (hi, lo, rows) as split_planes does."""
+    lib = _lib()
+    rows = round_up(Q.shape[0], 128)
+    lib.pfhip_op_plane_image_bytes.restype = ctypes.c_size_t
+    lib.pfhip_op_plane_image_bytes.argtypes = [_ci, _ci]
+    nb = int(lib.pfhip_op_plane_image_bytes(rows, n_head * 128))
+    hi = torch.zeros(nb, dtype=torch.uint8, device=Q.device)
+    lo = torch.zeros(nb, dtype=torch.uint8, device=Q.device)
+    lib.pfhip_op_attention_planes.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci,
+                                             ctypes.c_float, _vp]
+    _ck(lib.pfhip_op_attention_planes(_p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(hi), _p(lo), rows, _p(q_off),
+                                      _p(q_len), _p(kv_off), _p(kv_len), q_off.numel(), n_head, int(q_len.max().item()), Q.shape[0],
+                                      float(scale), _stream()), "attention_planes")
+    return hi, lo, rows
+
+
 def window_attention(Q, K, V, Lq, Lk, n_head, scale):
     """One streaming window: softmax(scale Q_h K_h^T) V_h for rows [0, Lq) x [0, Lk), d_k = 128."""
     O = torch.zeros((Q.shape[0], n_head * 128), dtype=torch.float32, device=Q.device)
@@ -223,15 +240,18 @@ def planes_to_float(hi, lo, rows, K):
 
 
 def gemm_p3(A_img, W_img, M, N, K, w_scale=1.0, bias=None, R1=None, relu=False, want_c=True, want_planes=False, ln_stats=None,
-            ln_tiles=0, ln_colsum=None, stats_out=None):
-    """A_img / W_img: (hi, lo, rows) from split_planes.  Returns (C or None, (hi, lo, rows) of C or None)."""
+            ln_tiles=0, ln_colsum=None, stats_out=None, out=None, out_planes=None):
+    """A_img / W_img: (hi, lo, rows) from split_planes.  Returns (C or None, (hi, lo, rows) of C or None).  out / out_planes: reuse
+    buffers of an earlier call (timing loops)."""
     lib = _lib()
     ah, al, ra = A_img
     wh, wl, rw = W_img
     Mp = round_up(M, 128)
-    C = torch.empty((Mp, N), dtype=torch.float32, device=ah.device) if want_c else None
+    C = (out if out is not None else torch.empty((Mp, N), dtype=torch.float32, device=ah.device)) if want_c else None
     P = None
-    if want_planes:
+    if want_planes and out_planes is not None:
+        P = out_planes
+    elif want_planes:
         nb = int(lib.pfhip_op_plane_image_bytes(Mp, N))
         P = (torch.zeros(nb, dtype=torch.uint8, device=ah.device), torch.zeros(nb, dtype=torch.uint8, device=ah.device), Mp)
     lib.pfhip_op_gemm_p3.argtypes = [_vp, _vp, _ci, _vp, _vp, _ci, ctypes.c_float, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _ci,

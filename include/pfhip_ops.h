@@ -50,6 +50,13 @@ int pfhip_op_attention(const float* Q, int ldq, const float* K, int ldk, const f
 int pfhip_op_attention_hd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                           const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                           int max_q_len, float scale, int head_dim, void* stream);
+/* The same block (d_k = 128, attention_x3.hip) with the context written as the two fp16 plane images that pfhip_op_gemm_p3 takes as
+ * its A operand ([K / 16][plane_rows][16] per plane, K = H * 128; row = q_off[b] + t) instead of fp32 rows: the encoder's
+ * attention -> output-projection hand-off on large batches.  total_q_rows = the number of rows the offsets span (<= plane_rows,
+ * plane_rows a multiple of 128). */
+int pfhip_op_attention_planes(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* planes_hi, void* planes_lo,
+                              int plane_rows, const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
+                              int max_q_len, int total_q_rows, float scale, void* stream);
 /* CIF integrate-and-fire (onnxruntime/src/paraformer-online.cpp:301-327) + tail slot. */
 int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
                  float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream);

@@ -205,7 +205,10 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
         assert n > 50
         err = np.abs(got["logp"][i][:n] - ref["logp"][:n]).max()
         assert err < 1e-3, err
-        assert err < 1e-4, err            # what fp32 end to end actually gives
+        # what fp32-grade arithmetic end to end actually gives: two equally exact GPU paths (plane-image operands, fp32 operands:
+        # tools/planes_check.py) sit 1e-5 .. 1e-4 from the restatement and 8e-6 .. 5e-5 from each other over eight utterances of
+        # this batch — rounding noise amplified through 50 layers, ids identical on all 32
+        assert err < 2e-4, err
     model.close()
 
 

@@ -146,6 +146,32 @@ def test_attention_rescale_branch(ops):
     _attn_case(ops, [40], [200], 13, spike=True)
 
 
+def test_attention_context_as_plane_images(ops):
+    """attention_x3.hip writing the context as the fp16 plane images gemm_p3.hip stages by DMA: the decoded planes equal the fp32
+    output of the same launch to the planes' 22 bits, rows of other utterances and pad rows untouched, and the images feed the
+    output projection (gemm_p3) directly."""
+    rng = np.random.default_rng(31)
+    H, dk = 4, 128
+    lens = [70, 300, 129, 500, 65]
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    M = sum(lens)
+    Q = rng.standard_normal((M, H * dk)).astype(np.float32)
+    K = rng.standard_normal((M, H * dk)).astype(np.float32)
+    V = rng.standard_normal((M, H * dk)).astype(np.float32)
+    dl = dev(np.asarray(lens, np.int32))
+    O = ops.attention(dev(Q), dev(K), dev(V), dev(off), dl, dev(off), dl, H, dk ** -0.5).cpu().numpy()
+    hi, lo, rows = ops.attention_planes(dev(Q), dev(K), dev(V), dev(off), dl, dev(off), dl, H, dk ** -0.5)
+    got = ops.planes_to_float(hi, lo, rows, H * dk)
+    assert rows == (M + 127) // 128 * 128
+    assert np.abs(got[:M] - O).max() <= 2.0 ** -22 * np.abs(O).max() + 2.0 ** -24
+    assert np.abs(got[M:]).max() == 0                      # pad rows of the (zero-filled) image were not written
+    W = (rng.standard_normal((512, 512)) / np.sqrt(512)).astype(np.float32)
+    ws = ops.best_w_scale(float(np.abs(W).max()))
+    C, _ = ops.gemm_p3((hi, lo, rows), ops.split_planes(dev(W), scale=ws), M, 512, 512, w_scale=ws)
+    ref = O.astype(np.float64) @ W.astype(np.float64).T
+    assert np.abs(C.cpu().numpy()[:M] - ref).max() < 3e-5
+
+
 def test_attention_random_ragged_shapes(ops):
     """Seeded random segment lengths up to 700 queries / keys (several 256-query workgroups, partial last key tiles, single
     rows) through the default dispatch: the BF16-split kernel when the longest query segment exceeds 64, the fp32 one below."""

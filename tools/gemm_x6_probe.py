@@ -46,18 +46,27 @@ for (M, N, K) in shapes:
                 Cp, _ = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=b, R1=R, relu=True, want_c=True)
             e1.record(); torch.cuda.synchronize()
             tp.append(e0.elapsed_time(e1) / 5)
-        tpp = []
+        tpp, tpb = [], []
+        _, Pbuf = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=b, relu=True, want_c=False, want_planes=True)
+        Cbuf = torch.empty_like(Cp)
         for r in range(10):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=b, relu=True, want_c=False, want_planes=True)
+                ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=b, relu=True, want_c=False, want_planes=True, out_planes=Pbuf)
             e1.record(); torch.cuda.synchronize()
             tpp.append(e0.elapsed_time(e1) / 5)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=b, R1=R, relu=True, want_c=True, want_planes=True, out=Cbuf, out_planes=Pbuf)
+            e1.record(); torch.cuda.synchronize()
+            tpb.append(e0.elapsed_time(e1) / 5)
         t = float(np.median(tp[2:])) * 1e-3
         t2 = float(np.median(tpp[2:])) * 1e-3
+        t3 = float(np.median(tpb[2:])) * 1e-3
         err = float((Cp[:M, :N].double() - ref).abs().max())
-        print(f"M={M:5d} N={N:5d} K={K:5d}:  p3 fp32-out: {t * 1e6:8.1f} us {2.0 * M * N * K / t / 1e12:6.1f} TF err {err:.1e}   planes-out: {t2 * 1e6:8.1f} us {2.0 * M * N * K / t2 / 1e12:6.1f} TF", flush=True)
+        print(f"M={M:5d} N={N:5d} K={K:5d}:  p3 fp32-out: {t * 1e6:8.1f} us {2.0 * M * N * K / t / 1e12:6.1f} TF err {err:.1e}   planes-out: {t2 * 1e6:8.1f} us {2.0 * M * N * K / t2 / 1e12:6.1f} TF   both: {t3 * 1e6:8.1f} us", flush=True)
     line = f"M={M:5d} N={N:5d} K={K:5d}:"
     for k in kinds:
         t = float(np.median(ts[k][2:])) * 1e-3

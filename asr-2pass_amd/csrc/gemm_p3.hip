@@ -24,6 +24,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 
 namespace pfhip {
@@ -373,6 +374,8 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
                     const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s) {
   if (M <= 0 || N <= 0) return;
   const int tiles_n = (N + kPN - 1) / kPN, n_tiles = ((M + kPM - 1) / kPM) * tiles_n;
+  static const int gw_env = [] { const char* e = getenv("PFHIP_P3_GW"); return e && *e ? atoi(e) : 0; }();      // experiments
+  if (gw_env > 0) gw = gw_env;
   gw = std::max(1, std::min(gw, tiles_n));
   const int out = (C ? 1 : 0) | (Ph ? 2 : 0);
   const float inv = 1.0f / w_scale;

@@ -450,7 +450,8 @@ def main():
                 # achieved = ALGORITHMIC fp32 flops (2*M*N*K) per second; the dominant kernel executes 3 fp16 MFMAs per block (6 bf16
                 # ones with PFHIP_GEMM_X3=0), so its ceiling is the FP16 / BF16 dense peak / 3 (/ 6); executed MFMA rate = 3 x achieved
                 "bound": "mfma",
-                "kernel": "gemm_f32_f16x3_128_kernel / gemm_f32_f16x3_kernel" if x3 else "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel",
+                "kernel": ("gemm_p3_128_kernel (encoder, operands as fp16 plane images) / gemm_f32_f16x3_128_kernel (decoder)"
+                           if os.environ.get("PFHIP_PLANES", "1") != "0" else "gemm_f32_f16x3_128_kernel / gemm_f32_f16x3_kernel") if x3 else "gemm_f32_bf16x6_128_kernel / gemm_f32_bf16x6_kernel",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
                 "note": "flops counted = 2*M*N*K of the GEMMs only (the same launches also carry the LayerNorms folded into them). "
                         "Round 3 halved the MFMAs per block (3 fp16 products instead of 6 bf16 ones: ceiling 417 -> 833 TFLOP/s): the "

@@ -44,7 +44,7 @@ def main():
         w_mb = sum(w) / len(w) / 1024.0
         kernels.append({"kernel": key[0], "blocks": key[1], "calls": len(f), "fetch_size_kb_raw": sum(f) / len(f),
                         "fetch_mb_x2": f_mb, "write_mb": w_mb})
-        if key[0].startswith("gemm_f32_"):
+        if key[0].startswith(("gemm_f32_", "gemm_p3_")):
             gemm_bytes += (f_mb + w_mb) * 1024 * 1024 * len(f)
             gemm_launches += len(f)
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 "

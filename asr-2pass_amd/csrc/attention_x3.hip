@@ -15,6 +15,8 @@
 // must stay below 65504 — they are LayerNorm-ed activations times a weight matrix.
 // K / V tiles are split while they are staged (global fp32 -> registers -> fp16 planes in LDS; V transposed on the way by
 // loading 4 keys x 2 d per thread), double-buffered, one barrier per tile.
+// Output: fp32 rows, or — the encoder on large batches — the context as the two fp16 plane images that the output projection
+// (gemm_p3.hip) stages by LDS-DMA; then no fp32 context is written at all.
 #include "kernels.h"
 
 #include <math.h>

@@ -21,6 +21,8 @@
 // stage it has just finished reading; `s_waitcnt vmcnt(8)` + the step barrier retire K-step k + 2's DMA two full steps after issue.
 // Epilogues: fp32 C (bias, LayerNorm-fold finish, residual, ReLU, row statistics — as gemm_x3.hip), plane images of C for the
 // next GEMM, or both.
+// In the model (pfhip.cpp, batches of 6000+ rows): QKV' <LN, fp32>, out-projection <fp32 + planes + statistics> on the planes the
+// attention writes, FFN1' <LN, planes>, FFN2 <fp32 + planes + statistics>.
 #include "kernels.h"
 
 #include <algorithm>

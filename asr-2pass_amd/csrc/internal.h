@@ -138,6 +138,7 @@ struct pfhip_model {
   // ffn2 }, each image hi plane then lo plane.  wp_layer_bytes = 0: not built (the fp32 path serves every batch size).
   unsigned char* d_wplanes = nullptr;
   size_t wp_layer_bytes = 0, wp_off_out = 0, wp_off_ffn1 = 0, wp_off_ffn2 = 0;
+  int plane_forwards = 0;                                       // forwards of this context that took the plane path (debug read-out)
   Buf ctxP, xP, hP;                                             // activation plane images of a large batch: context, residual stream, FFN hidden
   // the same for the decoder's FFN: ffn1 with norm1, ffn2 with ffn_norm; [dec_layers + 1] entries (the last one is dec3)
   float* d_dlnw1 = nullptr; float* d_dlnb1 = nullptr; float* d_dlns1 = nullptr;

@@ -591,6 +591,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   static const int planes_min_rows = [] { const char* e = getenv("PFHIP_PLANES_MIN_ROWS"); return e && *e ? atoi(e) : 6000; }();
   const bool planes = fuse_ln && mem_in_x && m->wp_layer_bytes != 0 && M >= planes_min_rows && pfhip::attention_planes_ok(m->maxT);
   if (planes) {
+    ++m->plane_forwards;
     const size_t pd = pfhip::plane_image_bytes(Mp, d), pf = pfhip::plane_image_bytes(Mp, c.ffn);
     HIP_TRY(m->ctxP.ensure(2 * pd));
     HIP_TRY(m->xP.ensure(2 * pd));
@@ -1603,6 +1604,7 @@ pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
   std::lock_guard<std::mutex> lk(m->mu);
   if (std::string(what) == "blstm_flag") { m->debug_blstm_flag = value; return PFHIP_OK; }
   if (std::string(what) == "blstm_fallbacks") return (pfhip_status)m->blstm_fallbacks;      // read-out: how often the per-step form ran
+  if (std::string(what) == "plane_forwards") return (pfhip_status)m->plane_forwards;        // read-out: forwards on plane-image operands
   return fail(PFHIP_ERR_ARG, std::string("unknown debug key ") + what);
 }
 

@@ -351,7 +351,8 @@ pfhip_status pfhip_group_stats(pfhip_model* m, int* devices, int64_t* calls, int
 
 /* Test hook, not part of the serving path: "blstm_flag" (value != 0) raises the timestamp head's error word for the next
  * timestamp request only — as a step-barrier time-out of the persistent BLSTM kernel would — which then has to be served by the
- * per-step recurrence; "blstm_fallbacks" returns (as the status value) how many requests were served that way. */
+ * per-step recurrence; "blstm_fallbacks" returns (as the status value) how many requests were served that way; "plane_forwards"
+ * how many forwards of this context ran the encoder on plane-image operands (gemm_p3.hip: batches of PFHIP_PLANES_MIN_ROWS+ rows). */
 pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value);
 pfhip_status pfhip_profile_enable(pfhip_model* m, int on);
 pfhip_status pfhip_profile_read(pfhip_model* m, pfhip_profile* out, int reset);

@@ -197,6 +197,7 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
     rng = np.random.default_rng(20251114)
     utts = [synth_pcm(i, 480000, rng) for i in range(32)]
     got = model.forward_ids(utts, want_logp=True)
+    assert model._lib.pfhip_debug_poke(model.handle, b"plane_forwards", 0) == 1      # the encoder ran on plane-image operands (gemm_p3.hip)
     for i in (3, 31):
         ref = P.forward_pcm(utts[i], W)
         assert int(got["token_num"][i]) == ref["token_num"]
@@ -231,6 +232,8 @@ def test_layernorm_folded_into_the_gemms_with_strong_gamma_beta(pkg, weights_mod
     W = P.Weights(man, blob)
     utts = [synth_pcm(i, 480000 - 1234 * (i % 9), rng) for i in range(n_utts)]
     got = model.forward_ids(utts, want_logp=True)
+    planes = model._lib.pfhip_debug_poke(model.handle, b"plane_forwards", 0)
+    assert planes == (1 if n_utts == 36 else 0)     # 18000 rows: LayerNorm folded into the plane-operand GEMMs; 2500 / 6000: fp32 operands
     if n_utts == 36:
         assert int(sum(got["n_frames"])) >= 4096 and int(sum(got["n_fires"])) >= 4096
     elif n_utts == 12:      # decoder rows between the two thresholds: its folded FFN2 (LayerNorm over 2048 columns) on 64-row tiles

@@ -785,6 +785,8 @@ static bool x6_enabled() {
   static const bool on = [] { const char* e = getenv("PFHIP_GEMM_X6"); return !(e && e[0] == '0'); }();
   return on;
 }
+// whether the large GEMMs run the fp16 two-plane form (gemm_x3.hip / gemm_p3.hip) — PFHIP_GEMM_X3=0 asks for the bf16 three-plane one
+bool gemm_f16_planes_form() { return x6_enabled() && x3_enabled(); }
 bool gemm_x6_ln_ok(int M) {
   static const bool ln_on = [] { const char* e = getenv("PFHIP_GEMM_LN"); return !(e && e[0] == '0'); }();
   // from the batch size at which the N = 512 launches (four column tiles per row panel) go to the BF16-split kernels at all

@@ -21,7 +21,7 @@
 // stage it has just finished reading; `s_waitcnt vmcnt(8)` + the step barrier retire K-step k + 2's DMA two full steps after issue.
 // Epilogues: fp32 C (bias, LayerNorm-fold finish, residual, ReLU, row statistics — as gemm_x3.hip), plane images of C for the
 // next GEMM, or both.
-// In the model (pfhip.cpp, batches of 6000+ rows): QKV' <LN, fp32>, out-projection <fp32 + planes + statistics> on the planes the
+// In the model (pfhip.cpp, batches of 3500+ rows): QKV' <LN, fp32>, out-projection <fp32 + planes + statistics> on the planes the
 // attention writes, FFN1' <LN, planes>, FFN2 <fp32 + planes + statistics>.
 #include "kernels.h"
 
@@ -255,6 +255,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
 #undef PFHIP_RB
 #undef PFHIP_DMA
 #undef PFHIP_DMA1
+#undef PFHIP_SB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last (redundant) DMAs must not land in the C tile
   __syncthreads();
 
@@ -348,6 +349,195 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   }
 }
 
+// ---- the 64 x 128 tile: grids that leave most of a round of 128 x 128 tiles empty (a few utterances, the long-audio flow's packed
+// forwards, streaming rounds).  Same loop, half the rows: 4 waves as 2 x 2 (each 32 x 64 = two MFMA tiles, six MFMAs and six
+// fragment reads per K-step), a stage of 12 KB (A hi | A lo | W hi | W lo), ring of four = 48 KB: THREE workgroups per CU.
+constexpr int kHM = 64;
+constexpr int kHAPlane = kHM * kPRowB;                  // 2,048 B: one plane of the A operand of one stage
+constexpr int kHWOff = 2 * kHAPlane;                    // the W planes start here
+constexpr int kHStage = kHWOff + 2 * kPPlane;           // 12,288 B
+constexpr int kHLds = kPRing * kHStage;                 // 49,152 B (the 64 x 132 C tile + row statistics need 34,304)
+static_assert(kHM * kPCs * 4 + kHM * 8 <= kHLds, "the C tile must fit the ring");
+template <bool LN, int OUT>
+__global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
+    const unsigned char* __restrict__ Ah, const unsigned char* __restrict__ Al, int rows_a, const unsigned char* __restrict__ Wh,
+    const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
+    int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
+    const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
+    float inv_scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  int tm, tn;
+  tile_of_block_p3(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
+  const int m0 = tm * kHM, n0 = tn * kPN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // DMA map: 12 chunks of 1 KB per K-step, three per wave: one of the four A chunks (plane wave >> 1, rows 32 (wave & 1) ..), and
+  // rows 32 wave .. of both W planes
+  const size_t ka = (size_t)rows_a * kPRowB, kw = (size_t)rows_w * kPRowB;
+  const unsigned char* const ga = ((wave >> 1) ? Al : Ah) + ((size_t)(m0 + 32 * (wave & 1))) * kPRowB + lane * 16;
+  const unsigned char* const gwh = Wh + ((size_t)(n0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gwl = Wl + ((size_t)(n0 + 32 * wave)) * kPRowB + lane * 16;
+  const int lds_a = (wave >> 1) * kHAPlane + (wave & 1) * 1024, lds_w = kHWOff + wave * 1024;
+#define PFHIP_DMA1(src, off)                                                                                           \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                              \
+                                   (__attribute__((address_space(3))) void*)(lds + (off)), 16, 0, 0);
+#define PFHIP_DMA(stage, ks)                                                                                          \
+  PFHIP_DMA1(ga + (size_t)(ks) * ka, (stage) * kHStage + lds_a) PFHIP_DMA1(gwh + (size_t)(ks) * kw, (stage) * kHStage + lds_w)     \
+  PFHIP_DMA1(gwl + (size_t)(ks) * kw, (stage) * kHStage + lds_w + kPPlane)
+
+  const int ra = wr * 32 + r, rb = wc * 64 + r;
+  const int a_fr = ra * kPRowB + ((h ^ ((ra >> 3) & 1)) << 4);
+  const int w_fr = kHWOff + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
+
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  half8 fa[2], fb[2][2], ga_[2], gb_[2][2];          // A [plane]; W [plane][tile]
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_M(acc, A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0); PFHIP_SB;
+#define PFHIP_RA(G, st, p) G[p] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kHStage + (p) * kHAPlane + a_fr));
+#define PFHIP_RB(G, st, p, i) G[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kHStage + (p) * kPPlane + w_fr + (i) * 32 * kPRowB));
+  // per accumulator: a_hi w_lo, a_lo w_hi, a_hi w_hi (the order of gemm_x3.hip and of the 128-row kernel: bit-identical results)
+#define PFHIP_STEP(FA, FB, GA, GB, wst, rst, kdma)                                                                    \
+  {                                                                                                                   \
+    PFHIP_DMA(wst, kdma) PFHIP_SB;                                                                                    \
+    PFHIP_M(acc0, FA[0], FB[1][0]) PFHIP_RA(GA, rst, 0) PFHIP_SB;                                                     \
+    PFHIP_M(acc1, FA[0], FB[1][1]) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                                  \
+    PFHIP_M(acc0, FA[1], FB[0][0]) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                                                  \
+    PFHIP_M(acc1, FA[1], FB[0][1]) PFHIP_RA(GA, rst, 1) PFHIP_SB;                                                     \
+    PFHIP_M(acc0, FA[0], FB[0][0]) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                                                  \
+    PFHIP_M(acc1, FA[0], FB[0][1]) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                                                  \
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+    PFHIP_SB;                                                                                                         \
+  }
+
+  const int nk = K / kPK;
+  auto kclamp = [&](int t) { return t < nk ? t : nk - 1; };
+  PFHIP_DMA(0, 0)
+  PFHIP_DMA(1, kclamp(1))
+  PFHIP_DMA(2, kclamp(2))
+  PFHIP_DMA(3, kclamp(3))
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
+  PFHIP_RA(fa, 0, 0) PFHIP_RA(fa, 0, 1)
+  PFHIP_RB(fb, 0, 0, 0) PFHIP_RB(fb, 0, 0, 1) PFHIP_RB(fb, 0, 1, 0) PFHIP_RB(fb, 0, 1, 1)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // stage 0 is free for the DMA of K-step 4
+#define PFHIP_S0(kt) PFHIP_STEP(fa, fb, ga_, gb_, 0, 1, kclamp((kt) + 4))
+#define PFHIP_S1(kt) PFHIP_STEP(ga_, gb_, fa, fb, 1, 2, kclamp((kt) + 5))
+#define PFHIP_S2(kt) PFHIP_STEP(fa, fb, ga_, gb_, 2, 3, kclamp((kt) + 6))
+#define PFHIP_S3(kt) PFHIP_STEP(ga_, gb_, fa, fb, 3, 0, kclamp((kt) + 7))
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 4) { PFHIP_S0(kt) PFHIP_S1(kt) PFHIP_S2(kt) PFHIP_S3(kt) }
+  if (kt < nk) PFHIP_S0(kt)
+  if (kt + 1 < nk) PFHIP_S1(kt)
+  if (kt + 2 < nk) PFHIP_S2(kt)
+#undef PFHIP_S0
+#undef PFHIP_S1
+#undef PFHIP_S2
+#undef PFHIP_S3
+#undef PFHIP_STEP
+#undef PFHIP_M
+#undef PFHIP_RA
+#undef PFHIP_RB
+#undef PFHIP_DMA
+#undef PFHIP_DMA1
+#undef PFHIP_SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last (redundant) DMAs must not land in the C tile
+  __syncthreads();
+
+  // ---- epilogue (as the 128-row kernel, half the rows) -------------------------------------------------------------------------------
+  float* const Cs = reinterpret_cast<float*>(lds);
+  {
+    float* cw = Cs + (wr * 32 + 4 * h) * kPCs + wc * 64 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ro = ((e & 3) + 8 * (e >> 2)) * kPCs;
+      cw[ro] = acc0[e];
+      cw[ro + 32] = acc1[e];
+    }
+  }
+  float2* const s_mr = reinterpret_cast<float2*>(lds + kHM * kPCs * 4);
+  if (LN && tid < kHM) s_mr[tid] = ln_mr;
+  __syncthreads();
+
+  if (OUT & 1) {
+    const int c4 = tid & 31, rsub = tid >> 5;
+    const int gcol = n0 + 4 * c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
+    if (bias && gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
+    float4 r1v[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int grow = m0 + pass * 8 + rsub;
+      r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 8 + rsub, grow = m0 + row;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * kPCs + 4 * c4);
+      v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
+      if (LN) {
+        const float2 mr = s_mr[row];
+        v.x = mr.y * (v.x - mr.x * cs4.x); v.y = mr.y * (v.y - mr.x * cs4.y); v.z = mr.y * (v.z - mr.x * cs4.z); v.w = mr.y * (v.w - mr.x * cs4.w);
+      }
+      v.x += bv.x + r1v[pass].x; v.y += bv.y + r1v[pass].y; v.z += bv.z + r1v[pass].z; v.w += bv.w + r1v[pass].w;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
+      if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
+    }
+    if (OUT & 2) __syncthreads();
+  }
+  if (OUT & 2) {      // plane images of C: 64 lanes = the tile's 64 rows = 2 KB per plane, contiguous
+    const int row = tid & 63, grow = m0 + row;
+    const float2 mr = (LN && OUT == 2) ? s_mr[row] : make_float2(0.f, 1.f);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = (tid >> 6) + 4 * jj;                    // 16-column group of the tile
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(Cs + row * kPCs + 16 * j + 4 * c);
+        v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+      }
+      if (OUT == 2) {
+        const int gc = n0 + 16 * j;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 s4 = LN ? *reinterpret_cast<const float4*>(ln_colsum + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[4 * c + e] * inv_scale;
+            if (LN) x = mr.y * (x - mr.x * ss[e]);
+            x += bb[e];
+            if (relu) x = fmaxf(x, 0.f);
+            v[4 * c + e] = x;
+          }
+        }
+      }
+      const int ksp = (n0 >> 4) + j;
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const float w8[8] = {v[8 * pc], v[8 * pc + 1], v[8 * pc + 2], v[8 * pc + 3], v[8 * pc + 4], v[8 * pc + 5], v[8 * pc + 6], v[8 * pc + 7]};
+        uint4 hh, ll;
+        split8(w8, hh, ll);
+        const size_t off = image_off(ksp, grow, pc, rows_p);
+        *reinterpret_cast<uint4*>(Ph + off) = hh;
+        *reinterpret_cast<uint4*>(Pl + off) = ll;
+      }
+    }
+  }
+}
+
 template <auto kern, class... Args>
 void launch_with_lds(int n_tiles, int lds_bytes, hipStream_t s, Args... args) {
   static std::atomic<unsigned long long> attr_done{0};      // > 64 KB of dynamic LDS needs the opt-in once per kernel and device
@@ -373,9 +563,14 @@ void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K
 
 void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                     void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
-                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s) {
+                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s, int tile_rows) {
   if (M <= 0 || N <= 0) return;
-  const int tiles_n = (N + kPN - 1) / kPN, n_tiles = ((M + kPM - 1) / kPM) * tiles_n;
+  const int tiles_n = (N + kPN - 1) / kPN;
+  // 64-row tiles (three workgroups per CU) when 128-row tiles would leave most of a round of 512 slots empty
+  static const int half_env = [] { const char* e = getenv("PFHIP_P3_HALF_TILES"); return e && *e ? atoi(e) : 400; }();
+  const bool half = tile_rows == kHM || (tile_rows != kPM && ((M + kPM - 1) / kPM) * tiles_n <= half_env);
+  const int tmr = half ? kHM : kPM;
+  const int n_tiles = ((M + tmr - 1) / tmr) * tiles_n;
   static const int gw_env = [] { const char* e = getenv("PFHIP_P3_GW"); return e && *e ? atoi(e) : 0; }();      // experiments
   if (gw_env > 0) gw = gw_env;
   gw = std::max(1, std::min(gw, tiles_n));
@@ -385,12 +580,18 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
   const unsigned char *wh = static_cast<const unsigned char*>(Wh), *wl = static_cast<const unsigned char*>(Wl);
   unsigned char *ph = static_cast<unsigned char*>(Ph), *pl = static_cast<unsigned char*>(Pl);
 #define PFHIP_P3(LNF, OUTM)                                                                                                     \
-  launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
-                                                 M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv)
+  {                                                                                                                             \
+    if (half)                                                                                                                   \
+      launch_with_lds<gemm_p3_64_kernel<LNF, OUTM>>(n_tiles, kHLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv); \
+    else                                                                                                                        \
+      launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv); \
+  }
   if (ln_stats) {
-    if (out == 1) PFHIP_P3(true, 1); else if (out == 2) PFHIP_P3(true, 2); else PFHIP_P3(true, 3);
+    if (out == 1) PFHIP_P3(true, 1) else if (out == 2) PFHIP_P3(true, 2) else PFHIP_P3(true, 3)
   } else {
-    if (out == 1) PFHIP_P3(false, 1); else if (out == 2) PFHIP_P3(false, 2); else PFHIP_P3(false, 3);
+    if (out == 1) PFHIP_P3(false, 1) else if (out == 2) PFHIP_P3(false, 2) else PFHIP_P3(false, 3)
   }
 #undef PFHIP_P3
 }

@@ -77,11 +77,13 @@ size_t plane_image_bytes(int rows, int K);
 void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K, float scale, void* hi, void* lo, hipStream_t s);
 void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                     void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
-                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s);
+                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s,
+                    int tile_rows = 0);      // 0: 64-row tiles when 128-row tiles would fill less than a round; 64 / 128 force one
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).
 bool gemm_x6_ln_ok(int M);
+bool gemm_f16_planes_form();      // the large GEMMs are on the fp16 two-plane form (not PFHIP_GEMM_X3=0 / PFHIP_GEMM_X6=0)
 void launch_gemm_f32_x6_ln(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                            int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, const float* ln_stats, int ln_tiles,
                            const float* ln_colsum, float* stats_out, hipStream_t s, float w_scale = 1.0f);

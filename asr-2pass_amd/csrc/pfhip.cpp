@@ -586,10 +586,12 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
   // the QKV rows stay fp32 (residual adds, the attention's own staging).  Same arithmetic as the in-loop split of gemm_x3.hip.
   struct Img { unsigned char* hi; unsigned char* lo; };
   Img ctxP{nullptr, nullptr}, xP{nullptr, nullptr}, hP{nullptr, nullptr};
-  // gemm_p3.hip has the 128 x 128 tile only: below ~256 tiles for the N = 512 launches (measured switch: 16 x 30 s = 8000 rows
-  // 17.5 ms against 17.85, 8 x 30 s = 4000 rows 12.8 against 12.3) the 64-row tiles of the fp32-operand kernels fill the chip better (PFHIP_PLANES_MIN_ROWS moves the switch, PFHIP_PLANES=0 at load removes the path)
-  static const int planes_min_rows = [] { const char* e = getenv("PFHIP_PLANES_MIN_ROWS"); return e && *e ? atoi(e) : 6000; }();
-  const bool planes = fuse_ln && mem_in_x && m->wp_layer_bytes != 0 && M >= planes_min_rows && pfhip::attention_planes_ok(m->maxT);
+  // Below ~3500 rows the fp32-operand kernels stay: measured with the 64-row tile of gemm_p3.hip, 16 x 30 s = 8000 rows 16.95 ms
+  // against 17.60, 8 x 30 s = 4000 rows 12.01 against 12.17, 4 x 30 s = 2000 rows 10.08 against 9.94 (PFHIP_PLANES_MIN_ROWS moves the
+  // switch, PFHIP_PLANES=0 at load removes the path)
+  static const int planes_min_rows = [] { const char* e = getenv("PFHIP_PLANES_MIN_ROWS"); return e && *e ? atoi(e) : 3500; }();
+  const bool planes = fuse_ln && mem_in_x && m->wp_layer_bytes != 0 && M >= planes_min_rows && pfhip::gemm_f16_planes_form() &&
+                      pfhip::attention_planes_ok(m->maxT);
   if (planes) {
     ++m->plane_forwards;
     const size_t pd = pfhip::plane_image_bytes(Mp, d), pf = pfhip::plane_image_bytes(Mp, c.ffn);

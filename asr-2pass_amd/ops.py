@@ -240,7 +240,7 @@ def planes_to_float(hi, lo, rows, K):
 
 
 def gemm_p3(A_img, W_img, M, N, K, w_scale=1.0, bias=None, R1=None, relu=False, want_c=True, want_planes=False, ln_stats=None,
-            ln_tiles=0, ln_colsum=None, stats_out=None, out=None, out_planes=None):
+            ln_tiles=0, ln_colsum=None, stats_out=None, out=None, out_planes=None, tile_rows=0):
     """A_img / W_img: (hi, lo, rows) from split_planes.  Returns (C or None, (hi, lo, rows) of C or None).  out / out_planes: reuse
     buffers of an earlier call (timing loops)."""
     lib = _lib()
@@ -255,8 +255,8 @@ def gemm_p3(A_img, W_img, M, N, K, w_scale=1.0, bias=None, R1=None, relu=False, 
         nb = int(lib.pfhip_op_plane_image_bytes(Mp, N))
         P = (torch.zeros(nb, dtype=torch.uint8, device=ah.device), torch.zeros(nb, dtype=torch.uint8, device=ah.device), Mp)
     lib.pfhip_op_gemm_p3.argtypes = [_vp, _vp, _ci, _vp, _vp, _ci, ctypes.c_float, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _ci,
-                                     _vp, _ci, _vp, _vp, _vp]
+                                     _vp, _ci, _vp, _vp, _ci, _vp]
     _ck(lib.pfhip_op_gemm_p3(_p(ah), _p(al), ra, _p(wh), _p(wl), rw, float(w_scale), _p(C), N if want_c else 0, _p(P[0]) if P else None,
                              _p(P[1]) if P else None, Mp, _p(bias), _p(R1), R1.stride(0) if R1 is not None else 0, M, N, K,
-                             1 if relu else 0, _p(ln_stats), ln_tiles, _p(ln_colsum), _p(stats_out), _stream()), "gemm_p3")
+                             1 if relu else 0, _p(ln_stats), ln_tiles, _p(ln_colsum), _p(stats_out), tile_rows, _stream()), "gemm_p3")
     return C, P

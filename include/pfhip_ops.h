@@ -30,12 +30,13 @@ int pfhip_op_gemm_f32_scaled(const float* A, int lda, const float* W, int ldw, f
 float pfhip_op_best_w_scale(float max_abs);
 /* Pre-split operands (csrc/gemm_p3.hip): plane images — two fp16 planes of an fp32 matrix, [K/16][rows][16] with the 16-byte halves
  * of a row swapped where row bit 3 is set; rows a multiple of 128 — and the GEMM that consumes and produces them:
- * C = A W^T (x 1 / w_scale, LayerNorm-fold finish, +bias, +R1, ReLU) as fp32 (C != NULL) and / or as plane images (Ph / Pl != NULL). */
+ * C = A W^T (x 1 / w_scale, LayerNorm-fold finish, +bias, +R1, ReLU) as fp32 (C != NULL) and / or as plane images (Ph / Pl != NULL).
+ * tile_rows: 0 = by grid size, 64 / 128 = that tile height (the results are bit-identical). */
 size_t pfhip_op_plane_image_bytes(int rows, int K);
 int pfhip_op_split_planes(const float* X, int ld, int rows_valid, int rows, int K, float scale, void* hi, void* lo, void* stream);
 int pfhip_op_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                      void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, int relu,
-                     const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, void* stream);
+                     const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int tile_rows, void* stream);
 /* LayerNormalization over the last axis. */
 int pfhip_op_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int M, int D,
                        int Dout, float eps, void* stream);

@@ -393,6 +393,14 @@ def test_gemm_on_pre_split_operands(ops, M, N, K, relu):
     assert np.abs(pl - ref).max() < tol + 2.0 ** -21 * np.abs(ref).max()
     C1, _ = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dR1, relu=relu, want_c=True, want_planes=False)
     assert np.array_equal(C1.cpu().numpy()[:M], C.cpu().numpy()[:M])
+    # both tile heights (64 x 128: three workgroups per CU for small grids; 128 x 128), every output form: bit-identical
+    for tr in (64, 128):
+        Ct, Pt = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dR1, relu=relu, want_c=True, want_planes=True, tile_rows=tr)
+        assert np.array_equal(Ct.cpu().numpy()[:M], C.cpu().numpy()[:M]), tr
+        assert np.array_equal(ops.planes_to_float(Pt[0], Pt[1], Pt[2], N)[:M], pl), tr
+        _, Pt2 = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), relu=relu, want_c=False, want_planes=True, tile_rows=tr)
+        Ct2, _ = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), relu=relu, want_c=True, want_planes=False, tile_rows=tr)
+        assert np.abs(ops.planes_to_float(Pt2[0], Pt2[1], Pt2[2], N)[:M] - Ct2.cpu().numpy()[:M]).max() <= 2.0 ** -21 * max(1.0, np.abs(ref).max()), tr
     ref2 = A.astype(np.float64) @ W.astype(np.float64).T + bias              # planes only: no residual (FFN1's form)
     if relu:
         ref2 = np.maximum(ref2, 0)

@@ -24,7 +24,8 @@ KCLASS_NAMES = ["gemm", "attention", "layernorm", "fsmn", "fbank", "cif", "head"
 
 # every symbol include/pfhip.h declares (tests check the built library exports exactly these)
 ABI_SYMBOLS = [
-    "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_create_group", "pfhip_group_size", "pfhip_group_stats", "pfhip_destroy",
+    "pfhip_last_error", "pfhip_create", "pfhip_create_from_memory", "pfhip_create_from_files", "pfhip_read_model_files", "pfhip_container_blob",
+    "pfhip_container_manifest", "pfhip_container_from_cache", "pfhip_container_free", "pfhip_onnx_summary", "pfhip_vad_create_from_files", "pfhip_punc_create_from_files", "pfhip_create_group", "pfhip_group_size", "pfhip_group_stats", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch", "pfhip_offline_forward_resident",
     "pfhip_set_batching", "pfhip_set_inflight", "pfhip_get_inflight", "pfhip_inflight_stats", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
@@ -90,6 +91,19 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_create_from_memory.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ci, ctypes.POINTER(vp)]
     lib.pfhip_destroy.argtypes = [vp]
     lib.pfhip_destroy.restype = None
+    cs = ctypes.c_char_p
+    lib.pfhip_create_from_files.argtypes = [cs, cs, cs, cs, cs, ci, ctypes.POINTER(vp)]
+    lib.pfhip_vad_create_from_files.argtypes = [cs, cs, cs, ci, ctypes.POINTER(vp)]
+    lib.pfhip_punc_create_from_files.argtypes = [cs, cs, ci, ctypes.POINTER(vp)]
+    lib.pfhip_read_model_files.argtypes = [cs, cs, cs, cs, cs, cs, ctypes.POINTER(vp)]
+    lib.pfhip_container_blob.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    lib.pfhip_container_blob.restype = vp
+    lib.pfhip_container_manifest.argtypes = [vp]
+    lib.pfhip_container_manifest.restype = cs
+    lib.pfhip_container_from_cache.argtypes = [vp]
+    lib.pfhip_container_free.argtypes = [vp]
+    lib.pfhip_container_free.restype = None
+    lib.pfhip_onnx_summary.argtypes = [cs, ctypes.c_char_p, ctypes.c_size_t]
     lib.pfhip_create_group.argtypes = [vp, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
     lib.pfhip_group_size.argtypes = [vp]
     lib.pfhip_group_stats.argtypes = [vp, vp, vp, vp, vp, ci]
@@ -158,6 +172,31 @@ def _check(lib, st):
         raise PfhipError(f"pfhip status {st}: {lib.pfhip_last_error().decode()}")
 
 
+def read_model_files(kind, model, second=None, hotword=None, cmvn=None, config=None):
+    """The reference's own file contract (com-define.h:52-88) -> (manifest dict, float32 blob, from_cache) through the C++ reader
+    in libpfhip.so (pfhip_read_model_files); kind in {"asr", "vad", "punc"}.  No device needed."""
+    lib = load_lib()
+    enc = lambda s: None if s is None else str(s).encode()
+    h = ctypes.c_void_p()
+    _check(lib, lib.pfhip_read_model_files(kind.encode(), enc(model), enc(second), enc(hotword), enc(cmvn), enc(config), ctypes.byref(h)))
+    try:
+        nbytes = ctypes.c_size_t()
+        ptr = lib.pfhip_container_blob(h, ctypes.byref(nbytes))
+        blob = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), shape=(nbytes.value // 4,)).copy() if nbytes.value else np.zeros(0, np.float32)
+        man = json.loads(lib.pfhip_container_manifest(h).decode())
+        return man, blob, bool(lib.pfhip_container_from_cache(h))
+    finally:
+        lib.pfhip_container_free(h)
+
+
+def onnx_summary(path):
+    """pfhip_onnx_summary: what the C++ wire-format walk saw in one .onnx file (dict)."""
+    lib = load_lib()
+    buf = ctypes.create_string_buffer(1024)
+    _check(lib, lib.pfhip_onnx_summary(str(path).encode(), buf, len(buf)))
+    return json.loads(buf.value.decode())
+
+
 class ParaformerHip:
     """Host-side mirror of `funasr::Model` for the offline Paraformer path.
 
@@ -178,14 +217,21 @@ class ParaformerHip:
         self.cfg = None
 
     # -- lifetime ----------------------------------------------------------------------------------
-    def InitAsr(self, am_model, am_cmvn=None, am_config=None, token_file=None, thread_num=1, device=0, devices=None):
-        """am_model: path prefix of `<prefix>.bin/.json`, or a (manifest dict, float32 blob) pair.
-        am_cmvn/am_config are folded into the container (cmvn.* tensors, config block).
+    def InitAsr(self, am_model, am_cmvn=None, am_config=None, token_file=None, thread_num=1, device=0, devices=None,
+                second_model=None, hw_model=None):
+        """am_model: path prefix of `<prefix>.bin/.json`, a (manifest dict, float32 blob) pair, or — with am_cmvn and am_config —
+        the string the reference passes (`<dir>/model.onnx`, `model_quant.onnx`, `model.torchscript`; second_model = the online
+        model's `decoder.onnx`, hw_model = `model_eb.onnx`): pfhip_create_from_files reads the reference's own files.
         devices=[0, 1, ...]: one replica per listed device behind this one handle (pfhip_create_group)."""
         if self._h:
             self._lib.pfhip_destroy(self._h)
             self._h = ctypes.c_void_p()
-        if isinstance(am_model, (tuple, list)):
+        if isinstance(am_model, str) and am_cmvn and am_config and not os.path.exists(am_model + ".bin"):
+            enc = lambda s: None if s is None else str(s).encode()
+            _check(self._lib, self._lib.pfhip_create_from_files(enc(am_model), enc(second_model), enc(hw_model), enc(am_cmvn), enc(am_config),
+                                                                device, ctypes.byref(self._h)))
+            self.cfg = read_model_files("asr", am_model, second_model, hw_model, am_cmvn, am_config)[0]["config"]
+        elif isinstance(am_model, (tuple, list)):
             man, blob = am_model
             blob = np.ascontiguousarray(blob, dtype=np.float32)
             if devices is not None:

@@ -47,6 +47,32 @@ pfhip_status pfhip_create(const char* weight_blob_path, const char* manifest_jso
                           pfhip_model** out);
 pfhip_status pfhip_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json,
                                       int device, pfhip_model** out);
+/* The same with the strings the reference itself passes — its own file contract (onnxruntime/include/com-define.h:52-88):
+ *   am_model     <dir>/model.onnx | model_quant.onnx (offline-stream.cpp:74-77, tpass-stream.cpp:62,68) | model.torchscript /
+ *                model_blade.torchscript (offline-stream.cpp:79-84: TorchScript archives are not opened, the ONNX file of the same
+ *                stem beside it is read) | a container x.pfhip.bin (am_config = its manifest)
+ *   second_model NULL, or the online model's decoder.onnx / decoder_quant.onnx (paraformer.cpp:56-121: en_model + de_model)
+ *   hw_model     NULL, or model_eb.onnx as handed to InitHwCompiler BEFORE InitAsr (offline-stream.cpp:60-72, paraformer.cpp:243-261)
+ *   am_cmvn      am.mvn, read as LoadCmvn does (paraformer.cpp:325-360)
+ *   am_config    config.yaml (LoadConfigFromYaml / LoadOnlineConfigFromYaml, paraformer.cpp:178-241)
+ * The weights are read by a dependency-free protobuf walk (anonymous transposed MatMul initializers named after their layer,
+ * LSTM gate order, dynamic quantisation folded back to float32); nothing in a model file is executed.  The converted container
+ * is cached beside the source as <stem>.pfhip.{bin,json} and reused while every source file keeps its size and mtime
+ * (PFHIP_MODEL_CACHE=0 switches the cache off; a read-only directory is not an error). */
+pfhip_status pfhip_create_from_files(const char* am_model, const char* second_model, const char* hw_model, const char* am_cmvn,
+                                     const char* am_config, int device, pfhip_model** out);
+/* The file-reading step on its own (no device needed): kind = "asr" | "vad" | "punc".  The blob / manifest pointers stay
+ * valid until pfhip_container_free. */
+typedef struct pfhip_container pfhip_container;
+pfhip_status pfhip_read_model_files(const char* kind, const char* model, const char* second, const char* hotword, const char* cmvn,
+                                    const char* config, pfhip_container** out);
+const float* pfhip_container_blob(const pfhip_container* c, size_t* bytes);
+const char* pfhip_container_manifest(const pfhip_container* c);
+int pfhip_container_from_cache(const pfhip_container* c);
+void pfhip_container_free(pfhip_container* c);
+/* What the wire-format walk sees in ONE .onnx file, as JSON: initializer count and bytes, node count, node inputs nobody
+ * produces (0 for a file read correctly), torch-style tensors and the sum of their values.  Inspection only. */
+pfhip_status pfhip_onnx_summary(const char* path, char* out, size_t cap);
 /* Replaces Paraformer::~Paraformer (paraformer.cpp:267-295). */
 void pfhip_destroy(pfhip_model* m);
 
@@ -211,6 +237,9 @@ pfhip_status pfhip_stream_get_tensor(pfhip_stream* s, const char* name, float* d
 typedef struct pfhip_vad pfhip_vad;
 pfhip_status pfhip_vad_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
                                           pfhip_vad** out);
+/* FsmnVad::InitVad(vad_model, vad_cmvn, vad_config, thread_num) with the reference's own strings (fsmn-vad.cpp:10-50:
+ * <vad-dir>/model.onnx | model_quant.onnx, am.mvn, config.yaml); see pfhip_create_from_files. */
+pfhip_status pfhip_vad_create_from_files(const char* vad_model, const char* vad_cmvn, const char* vad_config, int device, pfhip_vad** out);
 void pfhip_vad_destroy(pfhip_vad* v);
 pfhip_status pfhip_vad_reset(pfhip_vad* v);
 int pfhip_vad_num_classes(const pfhip_vad* v);
@@ -287,6 +316,10 @@ pfhip_status pfhip_post_process(const char* const* chars, const float* stamps, i
 typedef struct pfhip_punc pfhip_punc;
 pfhip_status pfhip_punc_create_from_memory(const void* blob, size_t blob_bytes, const char* manifest_json, int device,
                                            pfhip_punc** out);
+/* CTTransformer::InitPunc(punc_model, punc_config, token_file, thread_num)'s session load with the reference's own strings
+ * (ct-transformer.cpp:14-37: <punc-dir>/model.onnx | model_quant.onnx, config.yaml; model_conf.punc_list goes into the manifest's
+ * config.punc_list for the host tokenizer); see pfhip_create_from_files. */
+pfhip_status pfhip_punc_create_from_files(const char* punc_model, const char* punc_config, int device, pfhip_punc** out);
 void pfhip_punc_destroy(pfhip_punc* p);
 int pfhip_punc_num_classes(const pfhip_punc* p);
 pfhip_status pfhip_punc_infer(pfhip_punc* p, const int32_t* ids, int n, int32_t* punc_out, float* logits_out);

@@ -28,9 +28,9 @@ ABI_SYMBOLS = [
     "pfhip_container_manifest", "pfhip_container_from_cache", "pfhip_container_free", "pfhip_onnx_summary", "pfhip_vad_create_from_files", "pfhip_punc_create_from_files", "pfhip_create_group", "pfhip_group_size", "pfhip_group_stats", "pfhip_destroy",
     "pfhip_sample_rate", "pfhip_vocab_size", "pfhip_feat_dim", "pfhip_d_model",
     "pfhip_offline_forward", "pfhip_offline_enqueue", "pfhip_offline_fetch", "pfhip_offline_forward_resident",
-    "pfhip_set_batching", "pfhip_set_inflight", "pfhip_get_inflight", "pfhip_inflight_stats", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
+    "pfhip_set_batching", "pfhip_set_inflight", "pfhip_warm_up", "pfhip_get_inflight", "pfhip_inflight_stats", "pfhip_is_contextual", "pfhip_has_timestamp_head", "pfhip_hotword_embed", "pfhip_set_hotwords",
     "pfhip_extract_feats", "pfhip_get_tensor", "pfhip_debug_poke", "pfhip_profile_enable", "pfhip_profile_read",
-    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_forward_batch", "pfhip_set_stream_batching",
+    "pfhip_stream_create", "pfhip_stream_destroy", "pfhip_stream_reset", "pfhip_stream_forward", "pfhip_stream_last_path", "pfhip_stream_forward_batch", "pfhip_set_stream_batching",
     "pfhip_stream_set_debug", "pfhip_stream_get_tensor",
     "pfhip_vad_create_from_memory", "pfhip_vad_destroy", "pfhip_vad_reset", "pfhip_vad_num_classes", "pfhip_vad_forward",
     "pfhip_vad_forward_sil", "pfhip_vad_stream_create", "pfhip_vad_stream_destroy", "pfhip_vad_stream_reset",
@@ -118,6 +118,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_set_batching.argtypes = [vp, ci, ci]
     lib.pfhip_set_inflight.argtypes = [vp, ci]
     lib.pfhip_get_inflight.argtypes = [vp]
+    lib.pfhip_warm_up.argtypes = [vp, ci, ci]
     lib.pfhip_inflight_stats.argtypes = [vp, ctypes.POINTER(_SlotStats), ci, ctypes.POINTER(ci)]
     lib.pfhip_is_contextual.argtypes = [vp]
     lib.pfhip_hotword_embed.argtypes = [vp, vp, vp, ci, vp]
@@ -127,6 +128,7 @@ def load_lib() -> ctypes.CDLL:
     lib.pfhip_stream_destroy.restype = None
     lib.pfhip_stream_reset.argtypes = [vp]
     lib.pfhip_stream_forward.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.pfhip_stream_last_path.argtypes = [vp]
     lib.pfhip_stream_forward_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.pfhip_set_stream_batching.argtypes = [vp, ci, ci]
     lib.pfhip_stream_set_debug.argtypes = [vp, ci]
@@ -510,6 +512,11 @@ class ParaformerOnlineHip:
 
     def set_debug(self, on=True):
         _check(self._lib, self._lib.pfhip_stream_set_debug(self._h, 1 if on else 0))
+
+    def last_path(self):
+        """Which branch of ParaformerOnline::Forward the last call took (pfhip_stream_last_path): 2 = the one whose non-empty
+        text the reference ends with a blank (paraformer-online.cpp:585-587)."""
+        return int(self._lib.pfhip_stream_last_path(self._h))
 
     def Forward(self, din, len_=None, input_finished=False, cap=256):
         x = np.ascontiguousarray(din if len_ is None else np.asarray(din)[:len_], dtype=np.float32)

@@ -100,9 +100,18 @@ CTTransformerHip::~CTTransformerHip() {
 void CTTransformerHip::InitPunc(const std::string& punc_model, const std::string& punc_config, const std::string& token_file,
                                 int thread_num) {
   (void)thread_num;
-  std::string blob, man;
-  if (!ReadText(punc_model, blob) || !ReadText(punc_config, man) ||
-      pfhip_punc_create_from_memory(blob.data(), blob.size(), man.c_str(), device_, &handle_) != PFHIP_OK) {
+  // the reference's own strings (offline-stream.cpp:111-117, tpass-stream.cpp:104-109): <punc-dir>/model.onnx | model_quant.onnx,
+  // config.yaml (model_conf.punc_list, tokenizer.cpp:147-158), tokens.json — or a container pair x.pfhip.bin / .json
+  pfhip_container* c = nullptr;
+  std::string man;
+  if (pfhip_read_model_files("punc", punc_model.c_str(), nullptr, nullptr, nullptr, punc_config.c_str(), &c) == PFHIP_OK) {
+    size_t bytes = 0;
+    const float* blob = pfhip_container_blob(c, &bytes);
+    man = pfhip_container_manifest(c);
+    if (pfhip_punc_create_from_memory(blob, bytes, man.c_str(), device_, &handle_) != PFHIP_OK) handle_ = nullptr;
+    pfhip_container_free(c);
+  }
+  if (!handle_) {
     // the reference exits on a model-load failure (ct-transformer.cpp:19-26)
     std::fprintf(stderr, "Error when load punc hip model: %s\n", pfhip_last_error());
     std::exit(-1);
@@ -245,14 +254,22 @@ std::string CTTransformerOnlineHip::AddPunc(const char* sz_input, std::vector<st
   return result;
 }
 
-PuncModelHipBase* CreatePuncModelHip(const std::string& punc_dir, int thread_num, bool allow_online) {
-  const std::string blob = punc_dir + "/punc.pfhip.bin", man = punc_dir + "/punc.pfhip.json", tok = punc_dir + "/tokens.json";
-  if (!std::ifstream(blob) || !std::ifstream(man) || !std::ifstream(tok)) {
+PuncModelHipBase* CreatePuncModelHip(const std::string& punc_dir, int thread_num, bool allow_online, bool quantized) {
+  // tpass-stream.cpp:100-135 / offline-stream.cpp:105-129 with the file names of com-define.h:52-88
+  const std::string model = punc_dir + (quantized ? "/model_quant.onnx" : "/model.onnx"), config = punc_dir + "/config.yaml",
+                    tok = punc_dir + "/tokens.json";
+  const bool container = (bool)std::ifstream(punc_dir + "/punc.pfhip.bin") || (bool)std::ifstream(punc_dir + "/model.pfhip.bin");
+  if ((!std::ifstream(model) || !std::ifstream(config)) && !container) {
     std::fprintf(stderr, "PUNC model file is not exist, skip load punc model.\n");
     return nullptr;
   }
-  CTTransformerHip* m = allow_online && punc_dir.find("realtime") != std::string::npos ? new CTTransformerOnlineHip() : new CTTransformerHip();
-  m->InitPunc(blob, man, tok, thread_num);
+  if (!std::ifstream(tok)) {
+    std::fprintf(stderr, "PUNC model file is not exist, skip load punc model.\n");
+    return nullptr;
+  }
+  // the reference tests the MODEL PATH for the word (tpass-stream.cpp:124)
+  CTTransformerHip* m = allow_online && model.find("realtime") != std::string::npos ? new CTTransformerOnlineHip() : new CTTransformerHip();
+  m->InitPunc(model, config, tok, thread_num);
   // One AddPunc per handler thread, each a few Infer calls: merged into packed device passes.  `thread_num` is the server's
   // --model-thread-num (onnxruntime intra-op threads, default 1: funasr-wss-server.cpp:105-106), NOT the number of handler
   // threads, so merging does not depend on it: a caller that finds the model idle runs at once, company queues behind it.

@@ -55,7 +55,9 @@ class PuncTokenizerHip {
 class CTTransformerHip : public PuncModelHipBase {
  public:
   ~CTTransformerHip() override;
-  // punc_model = weight blob (<dir>/punc.pfhip.bin), punc_config = its JSON manifest, token_file = tokens.json
+  // punc_model = <punc-dir>/model.onnx | model_quant.onnx, punc_config = <punc-dir>/config.yaml, token_file = <punc-dir>/tokens.json
+  // as the reference passes them (offline-stream.cpp:111-127, tpass-stream.cpp:104-134) — or a container pair
+  // (x.pfhip.bin + its JSON manifest); a directory that holds only a converted container is found from the ONNX name
   void InitPunc(const std::string& punc_model, const std::string& punc_config, const std::string& token_file,
                 int thread_num) override;
   std::string AddPunc(const char* sz_input, std::string language = "zh-cn") override;
@@ -77,8 +79,8 @@ class CTTransformerOnlineHip : public CTTransformerHip {
   std::string AddPunc(const char* sz_input, std::vector<std::string>& arr_cache, std::string language = "zh-cn") override;
 };
 
-// tpass-stream.cpp:103-135 / offline-stream.cpp:108-128: <punc_dir>/punc.pfhip.{bin,json} + tokens.json; the realtime class when
-// the directory name contains "realtime" (the reference tests the model path for that word), nullptr when files are missing.
-PuncModelHipBase* CreatePuncModelHip(const std::string& punc_dir, int thread_num, bool allow_online);
+// tpass-stream.cpp:100-135 / offline-stream.cpp:105-129: <punc_dir>/model.onnx (model_quant.onnx with PUNC_QUANT) + config.yaml +
+// tokens.json; the realtime class when the model path contains "realtime" (the reference's test), nullptr when files are missing.
+PuncModelHipBase* CreatePuncModelHip(const std::string& punc_dir, int thread_num, bool allow_online, bool quantized = false);
 
 }  // namespace funasr

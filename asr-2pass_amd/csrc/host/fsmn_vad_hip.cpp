@@ -44,14 +44,23 @@ FsmnVadHip::~FsmnVadHip() {
 }
 
 void FsmnVadHip::InitVad(const std::string& vad_model, const std::string& vad_cmvn, const std::string& vad_config, int thread_num) {
-  (void)vad_cmvn; (void)thread_num;
-  std::string blob, man;
-  if (!ReadFile(vad_model, blob) || !ReadFile(vad_config, man) ||
-      pfhip_vad_create_from_memory(blob.data(), blob.size(), man.c_str(), device_, &handle_) != PFHIP_OK) {
-    std::fprintf(stderr, "Error when load vad hip model: %s\n", pfhip_last_error());
+  (void)thread_num;
+  // the reference's own strings (offline-stream.cpp:12-26, tpass-stream.cpp:12-26): <vad-dir>/model.onnx | model_quant.onnx, am.mvn,
+  // config.yaml — ReadModel + LoadCmvn + LoadConfigFromYaml (fsmn-vad.cpp:10-50) — or a container pair x.pfhip.bin / .json
+  pfhip_container* c = nullptr;
+  std::string man;
+  if (pfhip_read_model_files("vad", vad_model.c_str(), nullptr, nullptr, vad_cmvn.c_str(), vad_config.c_str(), &c) == PFHIP_OK) {
+    size_t bytes = 0;
+    const float* blob = pfhip_container_blob(c, &bytes);
+    man = pfhip_container_manifest(c);
+    if (pfhip_vad_create_from_memory(blob, bytes, man.c_str(), device_, &handle_) != PFHIP_OK) handle_ = nullptr;
+    pfhip_container_free(c);
+  }
+  if (!handle_) {
+    std::fprintf(stderr, "Error when load vad hip model: %s\n", pfhip_last_error());       // fsmn-vad.cpp:57-60
     std::exit(-1);
   }
-  vad_silence_duration_ = (int)ManifestNumber(man, "max_end_silence_time", 800);
+  vad_silence_duration_ = (int)ManifestNumber(man, "max_end_silence_time", 800);             // model_conf (fsmn-vad.cpp:36-38)
   vad_max_len_ = (int)ManifestNumber(man, "max_single_segment_time", 60000);
   vad_speech_noise_thres_ = (float)ManifestNumber(man, "speech_noise_thres", 0.9);
 }

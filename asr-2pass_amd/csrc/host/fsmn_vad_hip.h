@@ -36,9 +36,10 @@ class FsmnVadHip : public VadModelHipBase {
  public:
   FsmnVadHip() {}
   ~FsmnVadHip() override;
-  // vad_model = weight blob (<dir>/vad.pfhip.bin), vad_config = its JSON manifest (cmvn.* tensors are in the container;
-  // config keys max_end_silence_time / max_single_segment_time / speech_noise_thres as vad.yaml's, fsmn-vad.cpp:36-38,
-  // defaults 800 / 60000 / 0.9).  Exits on a load failure like the reference (:30-33).
+  // vad_model = <vad-dir>/model.onnx | model_quant.onnx, vad_cmvn = <vad-dir>/am.mvn, vad_config = <vad-dir>/config.yaml as the
+  // reference passes them (offline-stream.cpp:12-26) — or a container pair (x.pfhip.bin + its JSON manifest).  model_conf's
+  // max_end_silence_time / max_single_segment_time / speech_noise_thres are read as fsmn-vad.cpp:36-38 does (defaults
+  // 800 / 60000 / 0.9).  Exits on a load failure like the reference (:30-33, :57-60).
   void InitVad(const std::string& vad_model, const std::string& vad_cmvn, const std::string& vad_config, int thread_num) override;
   // fsmn-vad.cpp:240-256: scores of the whole buffer, a FRESH detector run with is_final = true, online = false.
   // The network caches carry over between calls unless input_finished (Forward, :129-134); Reset() zeroes them.

@@ -29,6 +29,7 @@ struct RecogResult {               // funasr::FUNASR_RECOG_RESULT (com-define.h)
   float snippet_time = 0.f;
   std::vector<std::vector<int>> seg_ids;
   std::vector<std::pair<int, int>> segs;
+  std::vector<int> online_ids;       // ids the streaming chunks of this call emitted (inspection)
 };
 
 bool ReadAll(const std::string& path, std::vector<char>& out) {
@@ -91,20 +92,55 @@ int FetchDynamic(const std::vector<std::pair<int, int>>& frames, const std::vect
 
 }  // namespace
 
-FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int thread_num, bool use_gpu, int batch_size) {
-  (void)use_gpu;                         // there is no CPU path
-  auto os = std::make_unique<OfflineStreamHip>();
-  const std::string dir = model_path[MODEL_DIR];
-  std::string tok = model_path.count(TOKEN_PATH) ? model_path[TOKEN_PATH] : dir + "/tokens.json";
-  { std::ifstream probe(tok); if (!probe) tok.clear(); }
-  os->asr.InitAsr(dir + "/model.pfhip.bin", "", dir + "/model.pfhip.json", tok, thread_num);      // exits on failure
-  os->asr.SetBatchSize(batch_size);
-  if (model_path.count(VAD_DIR) && !model_path[VAD_DIR].empty()) {
-    os->vad.reset(new funasr::FsmnVadHip());
-    os->vad->InitVad(model_path[VAD_DIR] + "/vad.pfhip.bin", "", model_path[VAD_DIR] + "/vad.pfhip.json", thread_num);   // exits on failure
+namespace {
+bool FileExists(const std::string& path) { return (bool)std::ifstream(path); }
+std::string PathAppend(const std::string& dir, const std::string& name) { return dir.empty() || dir.back() == '/' ? dir + name : dir + "/" + name; }
+bool IsTrue(std::map<std::string, std::string>& model_path, const char* key) { return model_path.count(key) && model_path[key] == "true"; }
+// a directory converted ahead of time holds no model.onnx; the loader finds its container from the ONNX name
+bool HasContainer(const std::string& dir, const char* legacy) {
+  return FileExists(PathAppend(dir, "model.pfhip.bin")) || FileExists(PathAppend(dir, std::string(legacy) + ".pfhip.bin"));
+}
+// the VAD block both stream classes open with (offline-stream.cpp:6-29, tpass-stream.cpp:6-29)
+std::unique_ptr<funasr::FsmnVadHip> MakeVad(std::map<std::string, std::string>& model_path, int thread_num) {
+  if (!model_path.count(VAD_DIR) || model_path[VAD_DIR].empty()) return nullptr;
+  const std::string dir = model_path[VAD_DIR];
+  const std::string vad_model_path = PathAppend(dir, IsTrue(model_path, VAD_QUANT) ? QUANT_MODEL_NAME : MODEL_NAME);
+  const std::string vad_cmvn_path = PathAppend(dir, VAD_CMVN_NAME), vad_config_path = PathAppend(dir, VAD_CONFIG_NAME);
+  if (!HasContainer(dir, "vad") && (!FileExists(vad_model_path) || !FileExists(vad_cmvn_path) || !FileExists(vad_config_path))) {
+    std::fprintf(stderr, "VAD model file is not exist, skip load vad model.\n");
+    return nullptr;
   }
-  if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
-    os->punc.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, false));       // always CTTransformer here
+  std::unique_ptr<funasr::FsmnVadHip> vad(new funasr::FsmnVadHip());
+  vad->InitVad(vad_model_path, vad_cmvn_path, vad_config_path, thread_num);      // exits on failure
+  return vad;
+}
+}  // namespace
+
+// OfflineStream::OfflineStream (offline-stream.cpp:4-129) on the HIP plug-ins, call for call
+FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int thread_num, bool use_gpu, int batch_size) {
+  auto os = std::make_unique<OfflineStreamHip>();
+  os->vad = MakeVad(model_path, thread_num);
+  if (model_path.count(MODEL_DIR)) {
+    const std::string dir = model_path[MODEL_DIR];
+    os->asr.SetBatchSize(batch_size);                                            // :41 (before InitAsr)
+    const std::string hw_cpu_model_path = PathAppend(dir, MODEL_EB_NAME), hw_gpu_model_path = PathAppend(dir, TORCH_MODEL_EB_NAME);
+    const std::string seg_dict_path = PathAppend(dir, MODEL_SEG_DICT);
+    if (FileExists(hw_cpu_model_path)) {                                         // :63-67 if model_eb.onnx exist, hotword enabled
+      os->asr.InitHwCompiler(hw_cpu_model_path, thread_num);
+      os->asr.InitSegDict(seg_dict_path);
+    }
+    if (use_gpu && FileExists(hw_gpu_model_path)) {                              // :68-72
+      os->asr.InitHwCompiler(hw_gpu_model_path, thread_num);
+      os->asr.InitSegDict(seg_dict_path);
+    }
+    std::string am_model_path = PathAppend(dir, IsTrue(model_path, QUANTIZE) ? QUANT_MODEL_NAME : MODEL_NAME);      // :74-77
+    if (use_gpu) am_model_path = PathAppend(dir, TORCH_MODEL_NAME);              // :79-84 (the ONNX file beside it is read)
+    std::string token_path = model_path.count(TOKEN_PATH_KEY) ? model_path[TOKEN_PATH_KEY] : PathAppend(dir, TOKEN_PATH);
+    if (!FileExists(token_path)) token_path.clear();                             // harness runs on synthetic models: ids as text
+    os->asr.InitAsr(am_model_path, PathAppend(dir, AM_CMVN_NAME), PathAppend(dir, AM_CONFIG_NAME), token_path, thread_num);   // :89, exits on failure
+  }
+  if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())               // :105-129, always CTTransformer here
+    os->punc.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, false, IsTrue(model_path, PUNC_QUANT)));
   return os.release();
 }
 
@@ -200,6 +236,7 @@ void FunASRFreeResult(FUNASR_RESULT result) { delete static_cast<RecogResult*>(r
 void FunOfflineUninit(FUNASR_HANDLE handle) { delete static_cast<OfflineStreamHip*>(handle); }
 const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->seg_ids; }
 const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->segs; }
+const std::vector<int>& FunASRGetOnlineIds(FUNASR_RESULT result) { return static_cast<RecogResult*>(result)->online_ids; }
 pfhip_model* FunOfflineGetAsrHandle(FUNASR_HANDLE handle) { return handle ? static_cast<OfflineStreamHip*>(handle)->asr.Handle() : nullptr; }
 
 
@@ -207,62 +244,70 @@ pfhip_model* FunOfflineGetAsrHandle(FUNASR_HANDLE handle) { return handle ? stat
 namespace {
 
 struct TpassStreamHip {               // funasr::TpassStream (tpass-stream.cpp): the shared models
-  funasr::ParaformerHip asr, asr_online;
-  funasr::FsmnVadHip vad;
+  funasr::ParaformerHip asr;          // ONE object holds the offline session and the online encoder / decoder (paraformer.cpp:134-154)
+  std::unique_ptr<funasr::FsmnVadHip> vad;
   std::unique_ptr<funasr::PuncModelHipBase> punc_online;      // TpassStream::punc_online_handle (tpass-stream.cpp:100-135)
 };
 
 struct TpassOnlineStreamHip {         // funasr::TpassOnlineStream (tpass-online-stream.cpp:14-15): per connection
   TpassStreamHip* shared = nullptr;
-  pfhip_stream* asr_online = nullptr;
+  std::unique_ptr<funasr::ParaformerOnlineHip> asr_online;      // asr_online_handle (tpass-online-stream.cpp:14-15)
   std::unique_ptr<funasr::FsmnVadOnlineHip> vad_online;
   pfhip_host::TpassAudio audio;
-  int chunk_len = 9600;
-  std::string online_res;
-  ~TpassOnlineStreamHip() {
-    if (asr_online) pfhip_stream_destroy(asr_online);
-  }
 };
 
 }  // namespace
 
+// TpassStream::TpassStream (tpass-stream.cpp:4-135) on the HIP plug-ins, call for call
 FUNASR_HANDLE FunTpassInit(std::map<std::string, std::string>& model_path, int thread_num) {
   auto ts = std::make_unique<TpassStreamHip>();
-  auto init = [&](funasr::ParaformerHip& m, const std::string& dir) {
-    std::string tok = dir + "/tokens.json";
-    { std::ifstream probe(tok); if (!probe) tok.clear(); }
-    m.InitAsr(dir + "/model.pfhip.bin", "", dir + "/model.pfhip.json", tok, thread_num);
-  };
-  init(ts->asr, model_path[MODEL_DIR]);
-  init(ts->asr_online, model_path[ONLINE_MODEL_DIR]);
-  ts->vad.InitVad(model_path[VAD_DIR] + "/vad.pfhip.bin", "", model_path[VAD_DIR] + "/vad.pfhip.json", thread_num);   // exits on failure
-  if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())
-    ts->punc_online.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, true));   // realtime or offline class
-  // One handler thread per connection in the server: their concurrent device calls are merged into batched passes.  Not keyed
-  // on `thread_num`: that is --model-thread-num (onnxruntime intra-op threads, default 1: funasr-wss-server-2pass.cpp:110,569;
-  // websocket-server-2pass.cpp:629), not the number of handler threads.  A leader stops waiting as soon as every open
-  // connection has queued, so a lone connection pays nothing.  0 in a *_WAIT_US knob switches a queue off.  (The 2nd-pass
-  // model's queue and contexts are set up by ParaformerHip::InitAsr.)
+  ts->vad = MakeVad(model_path, thread_num);
+  if (!model_path.count(OFFLINE_MODEL_DIR) || !model_path.count(ONLINE_MODEL_DIR)) {                 // :79-82
+    std::fprintf(stderr, "Can not find offline-model-dir or online-model-dir\n");
+    std::exit(-1);
+  }
+  const std::string mdir = model_path[MODEL_DIR], odir = model_path[ONLINE_MODEL_DIR];
+  const std::string hw_compile_model_path = PathAppend(mdir, MODEL_EB_NAME), seg_dict_path = PathAppend(mdir, MODEL_SEG_DICT);
+  if (FileExists(hw_compile_model_path) && FileExists(seg_dict_path)) {                             // :54-60
+    ts->asr.InitHwCompiler(hw_compile_model_path, thread_num);
+    ts->asr.InitSegDict(seg_dict_path);
+  }
+  const bool q = IsTrue(model_path, QUANTIZE);                                                       // :62-72
+  const std::string am_model_path = PathAppend(model_path[OFFLINE_MODEL_DIR], q ? QUANT_MODEL_NAME : MODEL_NAME);
+  const std::string en_model_path = PathAppend(odir, q ? QUANT_ENCODER_NAME : ENCODER_NAME);
+  const std::string de_model_path = PathAppend(odir, q ? QUANT_DECODER_NAME : DECODER_NAME);
+  auto tokens_or_none = [](const std::string& p) { return FileExists(p) ? p : std::string(); };
+  ts->asr.InitAsr(am_model_path, en_model_path, de_model_path, PathAppend(odir, AM_CMVN_NAME), PathAppend(mdir, AM_CONFIG_NAME),
+                  tokens_or_none(PathAppend(mdir, TOKEN_PATH)), tokens_or_none(PathAppend(odir, TOKEN_PATH)), thread_num,
+                  PathAppend(odir, AM_CONFIG_NAME));                                                 // :76-77, exits on failure
+  if (!ts->vad) {                                                                                    // tpass-online-stream.cpp:8-11
+    std::fprintf(stderr, "vad_handle is null\n");
+    std::exit(-1);
+  }
+  if (model_path.count(PUNC_DIR) && !model_path[PUNC_DIR].empty())                                   // :100-135, realtime or offline class
+    ts->punc_online.reset(funasr::CreatePuncModelHip(model_path[PUNC_DIR], thread_num, true, IsTrue(model_path, PUNC_QUANT)));
+  // One handler thread per connection in the server: the VAD's concurrent device calls are merged into batched passes (the
+  // online acoustic model's queue is set up by ParaformerHip::InitAsr).  Not keyed on `thread_num`: that is --model-thread-num
+  // (onnxruntime intra-op threads, default 1: funasr-wss-server-2pass.cpp:110,569), not the number of handler threads.
   {
     auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
-    pfhip_set_stream_batching(ts->asr_online.Handle(), knob("PFHIP_STREAM_WAIT_US", 3000), knob("PFHIP_STREAM_MAX", 128));
-    pfhip_set_vad_stream_batching(ts->vad.Handle(), knob("PFHIP_VAD_WAIT_US", 1000), knob("PFHIP_VAD_MAX", 256));
+    pfhip_set_vad_stream_batching(ts->vad->Handle(), knob("PFHIP_VAD_WAIT_US", 1000), knob("PFHIP_VAD_MAX", 256));
   }
   return ts.release();
 }
 
+// TpassOnlineStream::TpassOnlineStream (tpass-online-stream.cpp:4-19)
 FUNASR_HANDLE FunTpassOnlineInit(FUNASR_HANDLE tpass_handle, std::vector<int> chunk_size) {
   TpassStreamHip* ts = static_cast<TpassStreamHip*>(tpass_handle);
   if (!ts || chunk_size.size() != 3) return nullptr;
   auto os = std::make_unique<TpassOnlineStreamHip>();
   os->shared = ts;
-  os->vad_online.reset(new funasr::FsmnVadOnlineHip(&ts->vad));
-  if (pfhip_stream_create(ts->asr_online.Handle(), chunk_size.data(), &os->asr_online) != PFHIP_OK || !os->vad_online->ok()) {
+  os->vad_online.reset(new funasr::FsmnVadOnlineHip(ts->vad.get()));
+  os->asr_online.reset(new funasr::ParaformerOnlineHip(&ts->asr, chunk_size));
+  if (!os->asr_online->ok() || !os->vad_online->ok()) {
     std::fprintf(stderr, "FunTpassOnlineInit: %s\n", pfhip_last_error());
     return nullptr;
   }
-  // ParaformerOnline::chunk_len = chunk_size[1] * frame_shift(10 ms) * lfr_n(6) * 16 samples/ms (paraformer-online.cpp:40-43)
-  os->chunk_len = chunk_size[1] * 10 * 6 * 16;
   return os.release();
 }
 
@@ -283,23 +328,17 @@ FUNASR_RESULT FunTpassInferBuffer(FUNASR_HANDLE handle, FUNASR_HANDLE online_han
   // FsmnVadOnline::Infer (fsmn-vad-online.cpp:135-151) as the VAD of Audio::Split
   os->vad_online->SetConfig(vad_tail_sil, vad_max_len);
   auto vad_infer = [&](std::vector<float>& waves, bool fin) { return os->vad_online->Infer(waves, fin); };
-  os->audio.Split(vad_infer, os->chunk_len, input_finished, (pfhip_host::AsrType)mode);
+  os->audio.Split(vad_infer, os->asr_online->chunk_len, input_finished, (pfhip_host::AsrType)mode);
   pfhip_host::TpassFrame frame;
   while (os->audio.FetchChunck(frame)) {                                            // funasrruntime.cpp:538-566
-    std::vector<int32_t> ids(256);
-    int n_ids = 0;
-    std::string msg;
-    if (pfhip_stream_forward(os->asr_online, frame.data.data(), (int)frame.data.size(), frame.is_final ? 1 : 0, ids.data(),
-                             (int)ids.size(), &n_ids) == PFHIP_OK)
-      msg = ts->asr_online.TokensToString(std::vector<int>(ids.begin(), ids.begin() + n_ids));
-    else
-      std::fprintf(stderr, "FunTpassInferBuffer: %s\n", pfhip_last_error());
+    const std::string msg = os->asr_online->Forward(frame.data.data(), (int)frame.data.size(), frame.is_final);      // :540
+    res->online_ids.insert(res->online_ids.end(), os->asr_online->LastTokenIds().begin(), os->asr_online->LastTokenIds().end());
     if (mode == ASR_ONLINE) {
-      os->online_res += msg;
+      os->asr_online->online_res += msg;
       if (frame.is_final) {                                                         // funasrruntime.cpp:543-556
-        res->tpass_msg = os->online_res;
-        if (ts->punc_online) res->tpass_msg = ts->punc_online->AddPunc(os->online_res.c_str(), punc_cache[0]);
-        os->online_res.clear();
+        res->tpass_msg = os->asr_online->online_res;
+        if (ts->punc_online) res->tpass_msg = ts->punc_online->AddPunc(os->asr_online->online_res.c_str(), punc_cache[0]);
+        os->asr_online->online_res.clear();
       }
       res->msg += msg;
     } else if (mode == ASR_TWO_PASS) {

@@ -18,11 +18,31 @@
 #include <string>
 #include <vector>
 
-#define MODEL_DIR "model-dir"          // com-define.h:52-60 keys used by the offline path
-#define VAD_DIR "vad-dir"
-#define TOKEN_PATH "token-path"
+#define MODEL_DIR "model-dir"          // com-define.h:14-28 keys of the model_path map
+#define OFFLINE_MODEL_DIR "model-dir"
 #define ONLINE_MODEL_DIR "online-model-dir"
+#define VAD_DIR "vad-dir"
 #define PUNC_DIR "punc-dir"
+#define QUANTIZE "quantize"
+#define VAD_QUANT "vad-quant"
+#define PUNC_QUANT "punc-quant"
+#define TOKEN_PATH_KEY "token-path"    // (not a key of the reference: an optional override of <model-dir>/tokens.json for harness runs)
+// com-define.h:52-88 file names inside those directories
+#define MODEL_NAME "model.onnx"
+#define QUANT_MODEL_NAME "model_quant.onnx"
+#define MODEL_EB_NAME "model_eb.onnx"
+#define TORCH_MODEL_NAME "model.torchscript"
+#define TORCH_MODEL_EB_NAME "model_eb.torchscript"
+#define ENCODER_NAME "model.onnx"
+#define QUANT_ENCODER_NAME "model_quant.onnx"
+#define DECODER_NAME "decoder.onnx"
+#define QUANT_DECODER_NAME "decoder_quant.onnx"
+#define AM_CMVN_NAME "am.mvn"
+#define AM_CONFIG_NAME "config.yaml"
+#define VAD_CMVN_NAME "am.mvn"
+#define VAD_CONFIG_NAME "config.yaml"
+#define MODEL_SEG_DICT "seg_dict"
+#define TOKEN_PATH "tokens.json"
 
 typedef void* FUNASR_HANDLE;
 typedef void* FUNASR_RESULT;
@@ -31,9 +51,11 @@ typedef enum { RASR_NONE = -1, RASRM_CTC_GREEDY_SEARCH = 0 } FUNASR_MODE;      /
 typedef enum { ASR_OFFLINE = 0, ASR_ONLINE = 1, ASR_TWO_PASS = 2 } ASR_TYPE;   // funasrruntime.h:48-52
 typedef void (*QM_CALLBACK)(int cur_step, int n_total);
 
-// model_path: MODEL_DIR = directory holding model.pfhip.bin / model.pfhip.json (+ tokens.json unless TOKEN_PATH is given),
-// VAD_DIR = directory holding vad.pfhip.bin / vad.pfhip.json (absent or "" = no VAD: the buffer is one segment).
-// A model that fails to load ends the process like the reference (paraformer.cpp:43-46).
+// model_path as the reference's servers fill it (funasr-wss-server.cpp:203-320): MODEL_DIR / VAD_DIR / PUNC_DIR are directories in
+// the reference's layout (model.onnx | model_quant.onnx with QUANTIZE = "true" | model.torchscript with use_gpu, model_eb.onnx,
+// seg_dict, am.mvn, config.yaml, tokens.json); the constructor makes the calls of OfflineStream::OfflineStream
+// (offline-stream.cpp:4-129) on the HIP plug-ins.  A directory that holds a converted container (x.pfhip.{bin,json}) instead of
+// ONNX files works too.  A model that fails to load ends the process like the reference (paraformer.cpp:43-46).
 FUNASR_HANDLE FunOfflineInit(std::map<std::string, std::string>& model_path, int thread_num, bool use_gpu = true,
                              int batch_size = 1);
 // sz_buf: n_len BYTES of little-endian int16 PCM (wav_format "pcm"/"PCM"; anything else returns nullptr: the
@@ -71,6 +93,8 @@ void FunTpassUninit(FUNASR_HANDLE handle);
 // Inspection for tests: token ids per VAD segment in time order and the segments (samples) of the last result.
 const std::vector<std::vector<int>>& FunASRGetSegmentIds(FUNASR_RESULT result);
 const std::vector<std::pair<int, int>>& FunASRGetSegments(FUNASR_RESULT result);
+// ... the ids the streaming chunks of one FunTpassInferBuffer call emitted
+const std::vector<int>& FunASRGetOnlineIds(FUNASR_RESULT result);
 // ... and the C-ABI handle of the offline acoustic model behind a FunOfflineInit handle (pfhip_inflight_stats in the harnesses)
 struct pfhip_model;
 pfhip_model* FunOfflineGetAsrHandle(FUNASR_HANDLE handle);

@@ -15,9 +15,9 @@ namespace {
 // per calling thread
 thread_local std::vector<std::vector<int>> tl_last_ids;
 thread_local std::vector<std::vector<float>> tl_last_spans;
-// Vocab::Vector2StringV2 updates a member (`last_is_complete_english_`, vocab.h:22); the reference calls it unguarded from
-// every decoder thread.  Here the text step of concurrent Forward calls is serialised.
-std::mutex g_text_mu;
+// (Vocab::Vector2StringV2 updates a member, `last_is_complete_english_`, vocab.h:22, and the reference calls it unguarded from
+// every decoder thread; the stand-alone HostVocab keeps that flag in an atomic, the in-tree build uses the reference's own
+// class as the reference does.  No lock is taken around the text step.)
 }  // namespace
 
 ParaformerHip::ParaformerHip() {
@@ -28,7 +28,9 @@ ParaformerHip::ParaformerHip() {
 
 ParaformerHip::~ParaformerHip() {
   if (handle_) pfhip_destroy(handle_);
+  if (online_handle_) pfhip_destroy(online_handle_);
   delete vocab;
+  delete online_vocab;
   delete seg_dict_;
 #ifdef PFHIP_WITH_FUNASR
   delete lm_vocab;
@@ -36,38 +38,128 @@ ParaformerHip::~ParaformerHip() {
 #endif
 }
 
-void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
-                            const std::string& token_file, int thread_num) {
-  (void)am_cmvn;
-  if (pfhip_create(am_model.c_str(), am_config.c_str(), device_, &handle_) != PFHIP_OK) {
-    // the reference exits on a model-load failure (paraformer.cpp:43-46)
+namespace {
+
+int Knob(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
+// "key": "value" of the manifest's config block ("" when absent)
+std::string ManifestString(const char* man, const char* key) {
+  const std::string m = man ? man : "", k = std::string("\"") + key + "\": \"";
+  const size_t at = m.find(k);
+  if (at == std::string::npos) return "";
+  const size_t end = m.find('"', at + k.size());
+  return end == std::string::npos ? "" : m.substr(at + k.size(), end - at - k.size());
+}
+
+// The file-reading half of InitAsr: the reference's own files -> a device model.  Exits on failure like paraformer.cpp:43-46.
+pfhip_model* LoadModelFiles(const std::string& model, const std::string& second, const std::string& hotword, const std::string& cmvn,
+                            const std::string& config, int device, std::string* lang) {
+  pfhip_container* c = nullptr;
+  pfhip_model* h = nullptr;
+  if (pfhip_read_model_files("asr", model.c_str(), second.empty() ? nullptr : second.c_str(), hotword.empty() ? nullptr : hotword.c_str(),
+                             cmvn.c_str(), config.c_str(), &c) != PFHIP_OK) {
     std::fprintf(stderr, "Error when load am hip model: %s\n", pfhip_last_error());
     std::exit(-1);
   }
-  // `thread_num` is the server's --model-thread-num — onnxruntime intra-op threads, default 1 (funasr-wss-server.cpp:105-106,
-  // 452,511; websocket-server.cpp:433; used at paraformer.cpp:35) — NOT the number of decoder threads that share this handle
-  // (--decoder-thread-num, 8, or 16 in run_server_offline.sh:39).  It has no meaning here.  What the decoder threads get,
-  // whatever the flag says: their concurrent Forward calls are merged into packed launches (a lone caller never waits:
-  // pfhip_set_batching) and dealt to PFHIP_INFLIGHT execution contexts over the one weight set.
-  (void)thread_num;
-  auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
-  // A model with the timestamp head keeps ONE context unless told otherwise: its recurrence is a persistent kernel that owns two
-  // XCDs for ~7 ms per 32 x 30 s, and every other context's kernels — dealt round-robin over all eight XCDs — wait behind it
-  // (measured: 58.8 ms per batch with three contexts against 39.9 with one).
-  const int inflight = knob("PFHIP_INFLIGHT", pfhip_has_timestamp_head(handle_) ? 1 : 3);
+  size_t bytes = 0;
+  const float* blob = pfhip_container_blob(c, &bytes);
+  if (lang) *lang = ManifestString(pfhip_container_manifest(c), "lang");
+  const pfhip_status st = pfhip_create_from_memory(blob, bytes, pfhip_container_manifest(c), device, &h);
+  pfhip_container_free(c);
+  if (st != PFHIP_OK) {
+    std::fprintf(stderr, "Error when load am hip model: %s\n", pfhip_last_error());
+    std::exit(-1);
+  }
+  return h;
+}
+
+HipVocab* LoadVocab(const std::string& token_file) {
+  if (token_file.empty()) return nullptr;
+#ifdef PFHIP_WITH_FUNASR
+  return new Vocab(token_file.c_str());
+#else
+  HipVocab* v = new HipVocab();
+  if (!v->Load(token_file.c_str())) { delete v; v = nullptr; }
+  return v;
+#endif
+}
+
+}  // namespace
+
+void ParaformerHip::LoadOffline(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
+                                const std::string& token_file) {
+  if (handle_) { pfhip_destroy(handle_); handle_ = nullptr; }
+  std::string lang;
+  handle_ = LoadModelFiles(am_model, "", hw_model_, am_cmvn, am_config, device_, &lang);
+  if (!lang.empty()) language = lang;                           // LoadConfigFromYaml (paraformer.cpp:193-196)
+  asr_sample_rate_ = pfhip_sample_rate(handle_);                // frontend_conf.fs (:191)
+  if (use_hotword_ && !pfhip_is_contextual(handle_))
+    std::fprintf(stderr, "ParaformerHip: %s holds no hotword embedder (bias_embed / bias_encoder): hotwords are ignored\n", hw_model_.c_str());
+  // What the decoder threads get, whatever --model-thread-num says: their concurrent Forward calls are merged into packed
+  // launches (a lone caller never waits: pfhip_set_batching) and dealt to PFHIP_INFLIGHT execution contexts over the one weight set.
+  // A model with the timestamp head keeps ONE context unless told otherwise (see DESIGN §6 / the BLSTM notes).
+  const int inflight = Knob("PFHIP_INFLIGHT", pfhip_has_timestamp_head(handle_) ? 1 : 3);
   if (inflight > 1 && pfhip_set_inflight(handle_, inflight) != PFHIP_OK)
     std::fprintf(stderr, "ParaformerHip::InitAsr: %s (one forward at a time)\n", pfhip_last_error());
-  const int wait_us = knob("PFHIP_OFFLINE_WAIT_US", 3000);     // 0 = no merging
-  if (wait_us > 0) pfhip_set_batching(handle_, wait_us, knob("PFHIP_OFFLINE_MAX", 96));   // 96 merged utterances: +16 % over 32 on the long-audio flow
-  if (!token_file.empty()) {                                   // paraformer.cpp:47-48
-    delete vocab;
-#ifdef PFHIP_WITH_FUNASR
-    vocab = new Vocab(token_file.c_str());
-#else
-    vocab = new HipVocab();
-    if (!vocab->Load(token_file.c_str())) { delete vocab; vocab = nullptr; }
-#endif
-  }
+  const int wait_us = Knob("PFHIP_OFFLINE_WAIT_US", 3000);     // 0 = no merging
+  if (wait_us > 0) pfhip_set_batching(handle_, wait_us, Knob("PFHIP_OFFLINE_MAX", 96));   // 96 merged utterances: +16 % over 32 on the long-audio flow
+  delete vocab;
+  vocab = LoadVocab(token_file);                                // paraformer.cpp:47-48
+  // ParaformerTorch::WarmUp (paraformer-torch.cpp:59,477-520): a dummy forward inside InitAsr.  Here through every execution
+  // context, at the batch size the server was started with (SetBatchSize precedes InitAsr, offline-stream.cpp:41) and
+  // PFHIP_WARMUP_SECONDS of audio per utterance (default 30; 0 = no warm-up), so that each context's workspace is sized too.
+  const int warm_s = Knob("PFHIP_WARMUP_SECONDS", 30);
+  if (warm_s > 0 && pfhip_warm_up(handle_, batch_size_ > 0 ? batch_size_ : 1, warm_s * asr_sample_rate_) != PFHIP_OK)
+    std::fprintf(stderr, "ParaformerHip::InitAsr: warm-up failed: %s\n", pfhip_last_error());
+}
+
+void ParaformerHip::LoadOnline(const std::string& en_model, const std::string& de_model, const std::string& am_cmvn,
+                               const std::string& am_config, const std::string& token_file) {
+  if (online_handle_) { pfhip_destroy(online_handle_); online_handle_ = nullptr; }
+  // a container pair stands for both files of the online model
+  const bool container = en_model.size() > 10 && en_model.compare(en_model.size() - 10, 10, ".pfhip.bin") == 0;
+  online_handle_ = LoadModelFiles(en_model, container ? "" : de_model, "", am_cmvn, am_config, device_, nullptr);
+  asr_sample_rate_ = pfhip_sample_rate(online_handle_);
+  delete online_vocab;
+  online_vocab = LoadVocab(token_file);                         // paraformer.cpp:117
+  // One handler thread per connection in the server: their concurrent chunk calls are merged into batched passes; a leader
+  // stops waiting as soon as every open connection has queued, so a lone connection pays nothing.  0 switches the queue off.
+  pfhip_set_stream_batching(online_handle_, Knob("PFHIP_STREAM_WAIT_US", 3000), Knob("PFHIP_STREAM_MAX", 128));
+}
+
+// offline (paraformer.cpp:21-53)
+void ParaformerHip::InitAsr(const std::string& am_model, const std::string& am_cmvn, const std::string& am_config,
+                            const std::string& token_file, int thread_num) {
+  // `thread_num` is the server's --model-thread-num — onnxruntime intra-op threads, default 1 (funasr-wss-server.cpp:105-106,
+  // 452,511; websocket-server.cpp:433; used at paraformer.cpp:35) — NOT the number of decoder threads that share this handle
+  // (--decoder-thread-num, 8, or 16 in run_server_offline.sh:39).  It has no meaning here.
+  (void)thread_num;
+  LoadOffline(am_model, am_cmvn, am_config, token_file);
+}
+
+// online (paraformer.cpp:56-131)
+void ParaformerHip::InitAsr(const std::string& en_model, const std::string& de_model, const std::string& am_cmvn,
+                            const std::string& am_config, const std::string& token_file, int thread_num) {
+  (void)thread_num;
+  LoadOnline(en_model, de_model, am_cmvn, am_config, token_file);
+}
+
+// 2pass (paraformer.cpp:134-154): online first, then the offline session with the offline model's config and tokens
+void ParaformerHip::InitAsr(const std::string& am_model, const std::string& en_model, const std::string& de_model,
+                            const std::string& am_cmvn, const std::string& am_config, const std::string& token_file,
+                            const std::string& online_token_file, int thread_num, const std::string& online_config_file) {
+  (void)thread_num;
+  LoadOnline(en_model, de_model, am_cmvn, online_config_file, online_token_file);
+  LoadOffline(am_model, am_cmvn, am_config, token_file);
+}
+
+void ParaformerHip::InitAsr(const std::string& am_model, const std::string& en_model, const std::string& de_model,
+                            const std::string& am_cmvn, const std::string& am_config, const std::string& token_file,
+                            const std::string& online_token_file, int thread_num) {
+  InitAsr(am_model, en_model, de_model, am_cmvn, am_config, token_file, online_token_file, thread_num, am_config);
 }
 
 void ParaformerHip::InitLm(const std::string& lm_file, const std::string& lm_cfg_file, const std::string& lex_file) {
@@ -97,15 +189,31 @@ void ParaformerHip::InitLm(const std::string& lm_file, const std::string& lm_cfg
 #endif
 }
 
-int ParaformerHip::GetAsrSampleRate() { return handle_ ? pfhip_sample_rate(handle_) : 16000; }
+int ParaformerHip::GetAsrSampleRate() { return asr_sample_rate_; }
+
+std::string ParaformerHip::OnlineTokensToString(const std::vector<int>& ids) {
+  HipVocab* v = online_vocab ? online_vocab : vocab;
+  if (v) return v->Vector2StringV2(ids);                       // OnlineGreedySearch (paraformer.cpp:362-371): no language argument
+  std::string s;
+  for (size_t i = 0; i < ids.size(); ++i) {
+    if (i) s += ' ';
+    s += std::to_string(ids[i]);
+  }
+  return s;
+}
+
+std::string ParaformerHip::Forward(float* din, int len, bool input_finished, const std::vector<std::vector<float>>& hw_emb,
+                                   void* wfst_decoder) {
+  float* buff[1] = {din};
+  int lens[1] = {len};
+  const std::vector<std::string> r = Forward(buff, lens, input_finished, hw_emb, wfst_decoder, 1);
+  return r.empty() ? std::string() : r[0];
+}
 
 // Vocab::Vector2StringV2(hyps, language) (paraformer.cpp:396); without a token file (harness runs on synthetic models)
 // the ids themselves, space separated
 std::string ParaformerHip::IdsToString(const std::vector<int>& ids) {
-  if (vocab) {
-    std::lock_guard<std::mutex> lk(g_text_mu);
-    return vocab->Vector2StringV2(ids, language);
-  }
+  if (vocab) return vocab->Vector2StringV2(ids, language);
   std::string s;
   for (size_t i = 0; i < ids.size(); ++i) {
     if (i) s += ' ';
@@ -245,4 +353,53 @@ std::vector<std::vector<float>> ParaformerHip::CompileHotwordEmbedding(std::stri
 namespace funasr {
 const std::vector<std::vector<int>>& ParaformerHip::LastTokenIds() const { return tl_last_ids; }
 const std::vector<std::vector<float>>& ParaformerHip::LastTimestamps() const { return tl_last_spans; }
+}  // namespace funasr
+
+namespace funasr {
+
+ParaformerOnlineHip::ParaformerOnlineHip(ParaformerHipBase* offline_handle, std::vector<int> chunk_size, std::string model_type) {
+  (void)model_type;                                             // MODEL_PARA only (SenseVoice is out of scope)
+  offline_handle_ = dynamic_cast<ParaformerHip*>(offline_handle);
+  if (!offline_handle_ || !offline_handle_->OnlineHandle() || chunk_size.size() != 3) {
+    std::fprintf(stderr, "ParaformerOnlineHip: the shared model holds no online encoder / decoder (InitAsr with en_model, de_model)\n");
+    return;
+  }
+  if (pfhip_stream_create(offline_handle_->OnlineHandle(), chunk_size.data(), &stream_) != PFHIP_OK) {
+    std::fprintf(stderr, "ParaformerOnlineHip: %s\n", pfhip_last_error());
+    stream_ = nullptr;
+  }
+  // chunk_len = chunk_size[1] * frame_shift (10 ms) * lfr_n (6) * 16 samples per ms (paraformer-online.cpp:40-43)
+  chunk_len = chunk_size[1] * 10 * 6 * (offline_handle_->GetAsrSampleRate() / 1000);
+}
+
+ParaformerOnlineHip::~ParaformerOnlineHip() {
+  if (stream_) pfhip_stream_destroy(stream_);
+}
+
+void ParaformerOnlineHip::Reset() {
+  if (stream_) pfhip_stream_reset(stream_);
+}
+
+std::string ParaformerOnlineHip::Forward(float* din, int len, bool input_finished, const std::vector<std::vector<float>>& hw_emb,
+                                         void* wfst_decoder) {
+  (void)hw_emb; (void)wfst_decoder;                              // unused by ParaformerOnline::Forward too
+  last_ids_.clear();
+  if (!stream_ || !din || len < 0) return "";
+  std::vector<int32_t> ids(256);
+  int n_ids = 0;
+  pfhip_status st = pfhip_stream_forward(stream_, din, len, input_finished ? 1 : 0, ids.data(), (int)ids.size(), &n_ids);
+  if (st == PFHIP_ERR_CAPACITY) {                                // *n_tokens = what it needed; the chunk was not consumed
+    ids.resize((size_t)n_ids + 16);
+    st = pfhip_stream_forward(stream_, din, len, input_finished ? 1 : 0, ids.data(), (int)ids.size(), &n_ids);
+  }
+  if (st != PFHIP_OK) {
+    std::fprintf(stderr, "ParaformerOnlineHip::Forward: %s\n", pfhip_last_error());
+    return "";
+  }
+  last_ids_.assign(ids.begin(), ids.begin() + n_ids);
+  std::string result = offline_handle_->OnlineTokensToString(last_ids_);
+  if (!result.empty() && pfhip_stream_last_path(stream_) == 2) result.push_back(' ');      // paraformer-online.cpp:585-587
+  return result;
+}
+
 }  // namespace funasr

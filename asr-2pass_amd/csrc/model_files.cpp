@@ -1230,6 +1230,25 @@ std::string resolve_onnx(const std::string& path) {
   throw std::runtime_error("no ONNX file for " + path + " (looked for " + stem + ".onnx / " + stem + "_quant.onnx in " + dir + ")");
 }
 
+bool load_container_pair(const std::string& model, const std::string& config, Container& out);
+
+// A directory that holds no ONNX file but a container converted earlier (tools/convert_funasr.py, or this reader's own cache
+// after the sources were removed): <dir>/<stem>.pfhip.{bin,json}, or the names the stand-alone harnesses of rounds 1-3 used.
+bool preconverted(const std::string& model, const char* legacy_stem, Container& out) {
+  try {
+    (void)resolve_onnx(model);
+    return false;
+  } catch (const std::runtime_error&) {
+    const std::string dir = dir_of(model);
+    std::string stem = base_of(model);
+    const size_t dot = stem.find('.');
+    if (dot != std::string::npos) stem = stem.substr(0, dot);
+    for (const std::string& cand : {dir + "/" + stem + ".pfhip.bin", dir + "/model.pfhip.bin", dir + "/" + legacy_stem + ".pfhip.bin"})
+      if (exists(cand) && exists(cand.substr(0, cand.size() - 4) + ".json")) return load_container_pair(cand, "", out);
+    throw;
+  }
+}
+
 std::string slurp(const std::string& path) {
   const std::vector<char> v = read_file(path);
   return std::string(v.begin(), v.end());
@@ -1360,7 +1379,7 @@ bool has_key(const State& state, const std::string& key) {
 void load_asr(const std::string& model, const std::string& second, const std::string& hotword, const std::string& cmvn,
               const std::string& config, Container& out) {
   out = Container();
-  if (load_container_pair(model, config, out)) return;
+  if (load_container_pair(model, config, out) || preconverted(model, "model", out)) return;
   std::vector<std::string> onnx = {resolve_onnx(model)};
   if (!second.empty()) onnx.push_back(resolve_onnx(second));
   if (!hotword.empty()) onnx.push_back(resolve_onnx(hotword));
@@ -1434,7 +1453,7 @@ void load_asr(const std::string& model, const std::string& second, const std::st
 
 void load_vad(const std::string& model, const std::string& cmvn, const std::string& config, Container& out) {
   out = Container();
-  if (load_container_pair(model, config, out)) return;
+  if (load_container_pair(model, config, out) || preconverted(model, "vad", out)) return;
   const std::string onnx = resolve_onnx(model);
   const std::vector<std::string> files = {onnx, cmvn, config};
   const std::string prefix = cache_prefix(onnx);
@@ -1482,7 +1501,7 @@ void load_vad(const std::string& model, const std::string& cmvn, const std::stri
 
 void load_punc(const std::string& model, const std::string& config, Container& out) {
   out = Container();
-  if (load_container_pair(model, config, out)) return;
+  if (load_container_pair(model, config, out) || preconverted(model, "punc", out)) return;
   const std::string onnx = resolve_onnx(model);
   const std::vector<std::string> files = {onnx, config};
   const std::string prefix = cache_prefix(onnx);

@@ -139,6 +139,8 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   c.n_mels = (int)jc->number("n_mels", c.n_mels);
   c.lfr_m = (int)jc->number("lfr_m", c.lfr_m);
   c.lfr_n = (int)jc->number("lfr_n", c.lfr_n);
+  c.sample_rate = (int)jc->number("fs", c.sample_rate);           // frontend_conf.fs (paraformer.cpp:191)
+  if (c.sample_rate != 16000) return fail(PFHIP_ERR_UNSUPPORTED, "the front end is built for 16 kHz models (frontend_conf.fs)");
   c.pred_residual = (int)jc->number("pred_residual", 0);
   c.contextual = (int)jc->number("contextual", 0);
   c.timestamp = (int)jc->number("timestamp", 0);
@@ -1489,7 +1491,18 @@ pfhip_status pfhip_inflight_stats(pfhip_model* head, pfhip_slot_stats* out, int 
 pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwords) {
   g_err.clear();
   if (!m || !hw_emb || n_hotwords <= 0) return fail(PFHIP_ERR_ARG, "bad argument");
-  for (pfhip_model* r : all_slots(m)) {
+  // every context of every device, also those pfhip_set_inflight has taken off the slot list (they come back with a larger n)
+  std::vector<pfhip_model*> every;
+  {
+    std::lock_guard<std::mutex> l(m->bq.mu);
+    std::vector<pfhip_model*> devs{m};
+    for (pfhip_model* r : m->replicas) devs.push_back(r);
+    for (pfhip_model* d : devs) {
+      every.push_back(d);
+      for (pfhip_model* cx : d->contexts) every.push_back(cx);
+    }
+  }
+  for (pfhip_model* r : every) {
     std::lock_guard<std::mutex> lk(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     pfhip_status st = set_hotwords_locked(r, hw_emb, n_hotwords, r->own_stream);
@@ -1497,6 +1510,32 @@ pfhip_status pfhip_set_hotwords(pfhip_model* m, const float* hw_emb, int n_hotwo
   }
   std::lock_guard<std::mutex> l(m->bq.mu);
   m->hw_host.assign(hw_emb, hw_emb + (size_t)n_hotwords * m->cfg.d_model);
+  return PFHIP_OK;
+}
+
+// One synthetic batch through every execution slot: the code objects are loaded, each context's workspace is sized for
+// `batch` utterances of `n_samples` samples and its streams have run once, so the first real request pays none of that.
+pfhip_status pfhip_warm_up(pfhip_model* m, int batch, int n_samples) {
+  g_err.clear();
+  if (!m || batch <= 0 || n_samples <= 0 || batch > 1024 || n_samples > 16000 * 120) return fail(PFHIP_ERR_ARG, "bad argument");
+  if (m->group_head || m->weights_of) return fail(PFHIP_ERR_ARG, "not the handle pfhip_create returned");
+  std::vector<float> pcm((size_t)n_samples);
+  uint32_t lcg = 20251114u;
+  for (int i = 0; i < n_samples; ++i) {
+    lcg = lcg * 1664525u + 1013904223u;
+    pcm[i] = 0.15f * sinf(0.0431969f * (float)i) + 0.1f * ((float)(lcg >> 8) / 8388608.f - 1.f);
+  }
+  std::vector<const float*> ptrs((size_t)batch, pcm.data());
+  std::vector<int> lens((size_t)batch, n_samples);
+  const int max_tok = n_samples / 960 + 2;
+  std::vector<int32_t> ids((size_t)batch * max_tok), tn(batch), nf(batch), fr(batch);
+  std::vector<float> hw(m->cfg.contextual ? (size_t)m->cfg.d_model : 0, 0.f);
+  for (pfhip_model* r : all_slots(m)) {
+    pfhip_out out{};
+    out.token_ids = ids.data(); out.token_num = tn.data(); out.n_fires = nf.data(); out.n_frames = fr.data(); out.max_tokens = max_tok;
+    const pfhip_status st = forward_direct(r, ptrs.data(), lens.data(), batch, hw.empty() ? nullptr : hw.data(), hw.empty() ? 0 : 1, &out);
+    if (st) return st;
+  }
   return PFHIP_OK;
 }
 

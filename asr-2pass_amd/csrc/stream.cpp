@@ -38,6 +38,7 @@ struct pfhip_stream {
   int n_splice = 0;            // frames in the splice cache (front of fb[cur])
   int start_idx = 0;           // start_idx_cache_
   bool is_first_chunk = true, is_last_chunk = false;
+  int last_path = 0;           // which branch of ParaformerOnline::Forward the last call took (pfhip_stream_last_path)
   int n_featc = 10;            // rows in feats_cache_
   // device state
   Buf fb[2], rows, featc, chunk, carry, dcache;
@@ -654,6 +655,8 @@ void pfhip_stream_destroy(pfhip_stream* s) {
   delete s;
 }
 
+int pfhip_stream_last_path(const pfhip_stream* s) { return s ? s->last_path : 0; }
+
 pfhip_status pfhip_stream_reset(pfhip_stream* s) {
   last_error().clear();
   if (!s) return fail(PFHIP_ERR_ARG, "null stream");
@@ -689,8 +692,10 @@ pfhip_status prepare_first(Call& c, Recorder& rec) {
   pfhip_stream* s = c.s;
   pfhip_model* m = s->m;
   // (:532-540) a short final call after the first chunk: flush the look-back cache as the last chunk
+  s->last_path = 0;
   if (c.n_samples < 16 * 60 && c.fin && !s->is_first_chunk) {
     s->is_last_chunk = true;
+    s->last_path = 1;
     s->win_n = s->n_featc;
     rec.copy(Recorder::kWindow, s->chunk.f(), m->feat_pad, s->featc.f(), m->feat_dim, s->win_n, m->feat_dim);
     c.has_window = true;
@@ -702,8 +707,8 @@ pfhip_status prepare_first(Call& c, Recorder& rec) {
   if (rc) return rc;
   if (c.nr == 0) return PFHIP_OK;                                      // (:545-547)
   if (c.fin) {
-    if (c.nr + s->chunk_size[2] <= s->chunk_size[1]) s->is_last_chunk = true;      // (:557-559)
-    else c.second = true;                                                           // (:560-579) first chunk + last chunk
+    if (c.nr + s->chunk_size[2] <= s->chunk_size[1]) { s->is_last_chunk = true; s->last_path = 2; }      // (:557-559)
+    else { c.second = true; s->last_path = 3; }                                     // (:560-579) first chunk + last chunk
     c.reinit = true;
   }
   rc = add_overlap_chunk(s, 0, c.nr, c.fin, rec, &s->win_n);

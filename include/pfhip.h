@@ -139,6 +139,11 @@ pfhip_status pfhip_set_batching(pfhip_model* m, int wait_us, int max_utterances)
  * Call at initialisation (it may allocate); contexts of a replica group are created on every device.  The device-pointer form
  * (pfhip_offline_enqueue / _fetch), streams, pfhip_profile_* and pfhip_extract_feats use context 0. */
 pfhip_status pfhip_set_inflight(pfhip_model* m, int n);
+/* Replaces ParaformerTorch::WarmUp, the dummy forward the reference's GPU flavour runs inside InitAsr
+ * (onnxruntime/src/paraformer-torch.cpp:59,477-520): one synthetic batch of `batch` utterances x `n_samples` samples through
+ * EVERY execution slot (context x device), so that code objects are loaded and each context's workspace is sized before the
+ * first request.  Call after pfhip_set_inflight. */
+pfhip_status pfhip_warm_up(pfhip_model* m, int batch, int n_samples);
 int pfhip_get_inflight(const pfhip_model* m);
 /* One entry per execution slot (context x device) of the handle: packed device forwards run there, caller calls and utterances
  * they served.  utterances / forwards > calls / forwards > 1 is cross-request merging at work.  *n_out = slots (also on
@@ -204,6 +209,10 @@ void pfhip_stream_destroy(pfhip_stream* s);
 pfhip_status pfhip_stream_reset(pfhip_stream* s);
 pfhip_status pfhip_stream_forward(pfhip_stream* s, const float* pcm, int n_samples, int input_finished,
                                   int32_t* token_ids, int cap, int* n_tokens);
+/* Which branch of ParaformerOnline::Forward the stream's last call took: 0 not a final call (or no feature row), 1 the short
+ * final call that flushes the look-back cache (:532-540), 2 a final call whose rows fit one last chunk (:557-559; the only one
+ * whose non-empty text the reference ends with a blank, :585-587), 3 first chunk + last chunk (:560-579). */
+int pfhip_stream_last_path(const pfhip_stream* s);
 /* The same call for n_streams connections of ONE model at once (each stream at most once): every connection runs its own
  * ParaformerOnline::Forward control flow, and the encoder windows that are ready are packed into one forward (a 20-row
  * window costs the full weight stream and ~700 launches whatever its size).  Results are identical to n_streams separate

@@ -185,7 +185,8 @@ def test_cpp_2pass_api_matches_python_flow(pkg, weights_mod, tmp_path):
             fr = audio.FetchChunck()
             if fr is None:
                 break
-            online_txt += " ".join(str(i) for i in stream.Forward(fr["data"], input_finished=fr["is_final"]))
+            piece = " ".join(str(i) for i in stream.Forward(fr["data"], input_finished=fr["is_final"]))
+            online_txt += piece + (" " if piece and stream.last_path() == 2 else "")       # paraformer-online.cpp:585-587
         tpass_txt = ""
         while True:
             fr = audio.FetchTpass()

@@ -149,9 +149,9 @@ static_assert(kBlstmScratchFloats == 2 * 4 * kMaxB * kH + 8 && kBlstmFlagWord ==
 // stores into ring buffer (t + 1) % 4 and the readers POLL the data: every cell of a buffer holds the sentinel (+inf; |h| < 1)
 // until its value arrives, each lane re-reads its own 64 or 128 bytes until none of them is the sentinel.  One store -> L2 -> load
 // hand-off per step.  The ring has FOUR buffers so that the reset needs no wait of its own:
-//   step t: poll buffer t % 4 (h(t-1), complete once the poll ends) -> reset my cells of buffer (t + 3) % 4 to the sentinel (it
-//   held h(t-2), which every block finished reading before it published h(t-1), and I have just seen every h(t-1)) -> compute
-//   -> publish h(t) into buffer (t + 1) % 4.
+//   step t: poll buffer t % 4 (h(t-1)) -> MFMAs -> block barrier (now every wave's poll has ended: the block as a whole has seen
+//   every h(t-1)) -> reset my cells of buffer (t + 3) % 4 to the sentinel (it held h(t-2), which every block finished reading
+//   before it published h(t-1)) -> cell update -> publish h(t) into buffer (t + 1) % 4.
 //   A reader polls buffer (t + 3) % 4 at step t + 3, after it saw my h(t+1); I issued h(t+1) after my poll of step t + 1, whose
 //   `s_waitcnt vmcnt(0)` also waited for the acknowledgement of the reset of step t: the reset is in L2 before any reader can look,
 //   so nobody ever takes h(t-2) for h(t+2).
@@ -236,7 +236,6 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
         for (int s4 = 0; s4 < kKL / 4; ++s4) hb[s4] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    hreset[cell] = __builtin_bit_cast(float, kSentinelBits);
     if (t + 1 < Lmax) {
       const float* gp = gx_ptr(t + 1, live_n, frame_n);
 #pragma unroll
@@ -259,6 +258,11 @@ __global__ __launch_bounds__(kBlstmThreads, 1) void blstm_kernel(const float* __
         red[wave][16 + 4 * kq + r][((g ^ kq) * kUnits) + n] = acc[1][g][r] * kWScaleInv;
       }
     __syncthreads();
+    // EVERY wave of this block has finished its poll of step t by now, i.e. all 32 blocks have published h(t-1) — and a block
+    // publishes h(t-1) only after ITS poll of step t-1, its last read of h(t-2): nobody reads buffer (t + 3) % 4 any more.
+    // (Right after this wave's own poll that would not hold: a wave sees the h(t-1) of only the 4 blocks whose units fall in its
+    // k slice, while the cells it resets are read by all 32.)
+    hreset[cell] = __builtin_bit_cast(float, kSentinelBits);
     if (live) {
       float pre[4];
 #pragma unroll

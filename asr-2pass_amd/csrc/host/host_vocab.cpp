@@ -93,7 +93,7 @@ std::string HostVocab::Vector2StringV2(const std::vector<int>& in, const std::st
   };
 
   std::string glued;
-  bool gluing = false;
+  bool gluing = false, wrote = false, ends_complete_english = false;
   for (size_t i = 0; i < n; ++i) {
     std::string w = token(i);
     if (IsSpecial(w)) continue;
@@ -107,8 +107,12 @@ std::string HostVocab::Vector2StringV2(const std::vector<int>& in, const std::st
     }
     if (gluing) { w = glued + w; glued.clear(); gluing = false; }
     put(w);
-    last_is_complete_english_.store(i + 1 == n && !IsChinese(w) && !piece, std::memory_order_relaxed);           // (:283-288)
+    ends_complete_english = i + 1 == n && !IsChinese(w) && !piece;           // (:283-288)
+    wrote = true;
   }
+  // The reference writes the member after every word (false until the last one); sequentially only the last write is visible.
+  // Stored ONCE here, so that a concurrent call of another decoder thread never reads the mid-call "false" of this one.
+  if (wrote) last_is_complete_english_.store(ends_complete_english, std::memory_order_relaxed);
   return out;
 }
 

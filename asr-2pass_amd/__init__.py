@@ -472,6 +472,10 @@ class ParaformerHip:
             ns.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), B, ctypes.byref(out)))
         return dict(token_num=tn, n_fires=nf, n_frames=fr, ids=[ids[b, :min(tn[b], nf[b])].copy() for b in range(B)])
 
+    def debug_poke(self, what, value=0):
+        """pfhip_debug_poke: test hooks and read-outs ("range_flag", "range_fallbacks", "blstm_fallbacks", "plane_forwards")."""
+        return int(self._lib.pfhip_debug_poke(self._h, what.encode(), int(value)))
+
     def profile_enable(self, on=True):
         """on: False/0 off, True/1 every kernel class, other int = bit mask of classes (see pfhip.h)."""
         _check(self._lib, self._lib.pfhip_profile_enable(self._h, int(on)))
@@ -498,7 +502,8 @@ class ParaformerOnlineHip:
 
     def close(self):
         if self._h:
-            self._lib.pfhip_stream_destroy(self._h)
+            if self._model.handle:            # (a model closed first must not be touched through its stream)
+                self._lib.pfhip_stream_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -695,7 +700,8 @@ class FsmnVadOnlineHip:
 
     def close(self):
         if self._h:
-            self._lib.pfhip_vad_stream_destroy(self._h)
+            if self._vad._h:                  # a parent closed first (garbage collection order) took its streams' device state with it
+                self._lib.pfhip_vad_stream_destroy(self._h)
             self._h = ctypes.c_void_p()
             self._scorer.close()
 

@@ -294,7 +294,7 @@ void launch_attention_masked(const float* Q, int ldq, const float* K, int ldk, c
 // (attention_x6.hip, PFHIP_ATT_X3=0)
 static bool att_x3_on() {
   static const bool x3 = [] { const char* e = getenv("PFHIP_ATT_X3"); return !(e && e[0] == '0'); }();
-  return x3;
+  return x3 && !launch_ctx().exact;
 }
 static void launch_attention_split(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                                    const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len,

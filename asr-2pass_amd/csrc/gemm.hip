@@ -717,9 +717,13 @@ float best_w_scale(float max_abs) {
   e = std::max(-8, std::min(20, e - 1));
   return ldexpf(1.0f, e);                          // max_abs * scale <= 32768 < 65504
 }
+LaunchCtx& launch_ctx() {
+  static thread_local LaunchCtx ctx;
+  return ctx;
+}
 static bool x3_enabled() {
   static const bool on = [] { const char* e = getenv("PFHIP_GEMM_X3"); return !(e && e[0] == '0'); }();
-  return on;
+  return on && !launch_ctx().exact;
 }
 static void launch_split_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, const float* R1,
                               int ldr1, const float* R2, int ldr2, int M, int N, int K, bool relu, int gw, hipStream_t s, bool small_tile,

@@ -127,13 +127,16 @@ __device__ __forceinline__ void tile_row_stats(const float4& v, int grow, int M,
   const float q = half_wave_sum((a * a + b * b) + (c * c + d * d));
   if (c4 == 0 && grow < M) *reinterpret_cast<float2*>(stats + ((size_t)grow * tiles_n + tn) * 2) = make_float2(mean, q);
 }
-__device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, int tiles, float eps, int row) {
+// (a row whose rms leaves [2^-8, 2^12] raises the forward's range flag: gemm_x3.hip, kernels.h LaunchCtx)
+__device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, int tiles, float eps, int row, int* range_flag) {
   const float* sp = stats + (size_t)row * tiles * 2;
   float msum = 0.f, m2 = 0.f;
   for (int t = 0; t < tiles; ++t) msum += sp[2 * t];
   const float mean = msum / (float)tiles;
   for (int t = 0; t < tiles; ++t) { const float dm = sp[2 * t] - mean; m2 += sp[2 * t + 1] + (float)kPN * dm * dm; }
-  return make_float2(mean, 1.0f / sqrtf(m2 / (float)(tiles * kPN) + eps));
+  const float rstd = 1.0f / sqrtf(m2 / (float)(tiles * kPN) + eps);
+  if (range_flag && !(rstd > kLnRstdMin && rstd < kLnRstdMax)) atomicOr(range_flag, 2);
+  return make_float2(mean, rstd);
 }
 
 // OUT: 1 = fp32 C, 2 = plane images of C, 3 = both.  A / W images: rows_a / rows_w rows per K-step.  inv_scale = 1 / (weight scale).
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
     const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
     int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
     const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
-    float inv_scale) {
+    float inv_scale, int* range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   const int w_fr = 2 * kPPlane + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (LN && tid < kPM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
+  if (LN && tid < kPM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
     const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
     int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
     const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
-    float inv_scale) {
+    float inv_scale, int* range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   const int w_fr = kHWOff + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
+  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -583,10 +586,10 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
   {                                                                                                                             \
     if (half)                                                                                                                   \
       launch_with_lds<gemm_p3_64_kernel<LNF, OUTM>>(n_tiles, kHLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
-                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv); \
+                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
     else                                                                                                                        \
       launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
-                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv); \
+                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
   }
   if (ln_stats) {
     if (out == 1) PFHIP_P3(true, 1) else if (out == 2) PFHIP_P3(true, 2) else PFHIP_P3(true, 3)

@@ -159,13 +159,18 @@ __device__ __forceinline__ void tile_row_stats(const float4& v, int grow, int M,
 
 // the consumer's half.  Row statistics merged from the producer's per-tile pairs (Chan: n = 128 per tile) — one thread per row,
 // at kernel start, parked in registers under the K-loop and published through LDS for the epilogue passes ...
-__device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, int tiles, float eps, int row) {
+// A row whose rms lies outside [2^-8, 2^12] (or is not finite) is outside the domain the two fp16 planes of the raw residual
+// stream cover at fp32 grade: the forward's range flag is raised (kernels.h LaunchCtx) and the host redoes the batch on the
+// bf16 three-plane kernels.
+__device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, int tiles, float eps, int row, int* range_flag) {
   const float* sp = stats + (size_t)row * tiles * 2;
   float msum = 0.f, m2 = 0.f;
   for (int t = 0; t < tiles; ++t) msum += sp[2 * t];
   const float mean = msum / (float)tiles;
   for (int t = 0; t < tiles; ++t) { const float dm = sp[2 * t] - mean; m2 += sp[2 * t + 1] + (float)kBN * dm * dm; }
-  return make_float2(mean, 1.0f / sqrtf(m2 / (float)(tiles * kBN) + eps));
+  const float rstd = 1.0f / sqrtf(m2 / (float)(tiles * kBN) + eps);
+  if (range_flag && !(rstd > kLnRstdMin && rstd < kLnRstdMax)) atomicOr(range_flag, 2);
+  return make_float2(mean, rstd);
 }
 // ... where v (four columns of x W'^T) becomes rstd * (v - mean * colsum)
 __device__ __forceinline__ void ln_finish(float4& v, const float4& cs, float2 mr) {
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_128_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
     int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
-    const float* __restrict__ ln_colsum, float sw) {
+    const float* __restrict__ ln_colsum, float sw, int* range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_f16x3_128_kernel(
   // subtraction amplifies the accumulation error by about sqrt(mean^2 + var) / std of the row — a small factor for a residual
   // stream — where normalising on load did not, but on-load cost the 4-waves-per-SIMD loop 4 % (8 VALU ops per K-step).
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (LN && tid < kSM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
+  if (LN && tid < kSM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
   float4 xa, xw, ya, yw;
 #define PFHIP_LOAD_RAW(RA, RW, k0)                            \
   RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* C, int ldc,
     const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2, int M, int N, int K, int tiles_n,
     int n_tiles, int gw, int relu, const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, float* __restrict__ stats_out,
-    const float* __restrict__ ln_colsum, float sw) {
+    const float* __restrict__ ln_colsum, float sw, int* range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_f16x3_64_kernel(
   const int w_fr = 2 * kHPlaneA + (wc * 32 + r) * kHRowB + 16 * h;
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1));
+  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
   float4 xa, xw0, xw1, ya, yw0, yw1;
 #define PFHIP_LOAD_RAW(RA, RW0, RW1, k0)                      \
   RA = *reinterpret_cast<const float4*>(Ag + (k0));           \
@@ -802,10 +807,10 @@ void launch_gemm_f32_f16x3(const float* A, int lda, const float* W, int ldw, flo
 #define PFHIP_X3_LAUNCH_LN(KERN, TM, LDS)                                                                                        \
   {                                                                                                                              \
     const int n_tiles = ((M + (TM) - 1) / (TM)) * tiles_n;                                                                       \
-    if (ln_stats && sc) launch_with_lds<KERN<true, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);      \
-    else if (ln_stats) launch_with_lds<KERN<true, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);       \
-    else if (sc) launch_with_lds<KERN<false, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);            \
-    else launch_with_lds<KERN<false, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw);                    \
+    if (ln_stats && sc) launch_with_lds<KERN<true, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw, launch_ctx().range_flag);      \
+    else if (ln_stats) launch_with_lds<KERN<true, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw, launch_ctx().range_flag);       \
+    else if (sc) launch_with_lds<KERN<false, true>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw, launch_ctx().range_flag);            \
+    else launch_with_lds<KERN<false, false>>(n_tiles, LDS, s, A, lda, W, ldw, C, ldc, bias, R1, ldr1, R2, ldr2, M, N, K, tiles_n, n_tiles, gw, rl, ln_stats, ln_tiles, eps, stats_out, ln_colsum, sw, launch_ctx().range_flag);                    \
   }
   if (small_tile && half_tile) {
     PFHIP_X3_LAUNCH_LN(gemm_f32_f16x3_64_kernel, kHM, kHLdsBytes)

@@ -384,7 +384,7 @@ std::string ParaformerOnlineHip::Forward(float* din, int len, bool input_finishe
                                          void* wfst_decoder) {
   (void)hw_emb; (void)wfst_decoder;                              // unused by ParaformerOnline::Forward too
   last_ids_.clear();
-  if (!stream_ || !din || len < 0) return "";
+  if (!stream_ || len < 0 || (len > 0 && !din)) return "";       // (an empty final frame flushes the look-back cache, :532-540)
   std::vector<int32_t> ids(256);
   int n_ids = 0;
   pfhip_status st = pfhip_stream_forward(stream_, din, len, input_finished ? 1 : 0, ids.data(), (int)ids.size(), &n_ids);

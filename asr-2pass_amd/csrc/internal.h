@@ -138,6 +138,18 @@ struct pfhip_model {
   // ffn2 }, each image hi plane then lo plane.  wp_layer_bytes = 0: not built (the fp32 path serves every batch size).
   unsigned char* d_wplanes = nullptr;
   size_t wp_layer_bytes = 0, wp_off_out = 0, wp_off_ffn1 = 0, wp_off_ffn2 = 0;
+  // guard of the fp16 two-plane domain (pfhip.cpp fetch_locked): the forward's flag word (inside `meta`, cleared by the metadata
+  // upload), its pinned host mirror, what a re-run on the exact kernels needs, and the count of such re-runs
+  double static_bound = 0.0;          // load-time bound on |Linear(LayerNorm(x))| over the model's layers
+  bool always_exact = false;          // that bound reaches fp16's range: every forward runs the exact kernels
+  int* d_range_flag = nullptr;
+  int* h_flag = nullptr;
+  int range_hit = 0, debug_range_flag = 0;
+  bool exact_rerun = false, last_feats_only = false;
+  long long range_fallbacks = 0;
+  const float* last_pcm = nullptr;
+  std::vector<int64_t> last_off;
+  std::vector<int> last_n;
   int plane_forwards = 0;                                       // forwards of this context that took the plane path (debug read-out)
   Buf ctxP, xP, hP;                                             // activation plane images of a large batch: context, residual stream, FFN hidden
   // the same for the decoder's FFN: ffn1 with norm1, ffn2 with ffn_norm; [dec_layers + 1] entries (the last one is dec3)

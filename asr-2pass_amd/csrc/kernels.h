@@ -40,6 +40,21 @@ void launch_fbank_frames_batch(const float* pcm, const int64_t* sample_off, cons
 void launch_embed(const float* feats, int D, float* x0, int ldx, const int* row_pos, int M,
                   const float* inv_timescale, float scale, hipStream_t s);
 
+// ---- the fp16 two-plane domain guard ---------------------------------------------------------------------------------------
+// The default large-GEMM / attention forms stage their operands as two fp16 planes (gemm_x3.hip header): |a| >= 65504 overflows,
+// rows whose magnitude is far below 1 lose relative precision (absolute error 2^-25 per element).  A forward runs with a
+// per-thread launch context: `range_flag` (device word) is raised by the LayerNorm-folding kernels when a row's rms leaves
+// [2^-8, 2^11] (bit 1: no element of such a row of <= 512 values can reach 65504), by the LayerNorm kernel and by the head when
+// a row is not finite (bit 0: the check sits on the residual stream because ReLU swallows NaN); `exact` routes every split-operand launch of
+// the calling thread to the bf16 three-plane kernels (gemm_x6.hip / attention_x6.hip: fp32's exponent range, exact split) and
+// keeps the encoder off the plane images.  The reference computes in plain fp32 (onnxruntime/src/paraformer.cpp:496-541).
+struct LaunchCtx {
+  bool exact = false;
+  int* range_flag = nullptr;
+};
+LaunchCtx& launch_ctx();                      // thread-local (gemm.hip)
+constexpr float kLnRstdMin = 1.0f / 2048.0f, kLnRstdMax = 256.0f;
+
 // ---- dense ops --------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) (+R1[M,N]) (+R2[M,N]) (ReLU)   — fp32 MFMA 32x32x2.
 // A rows must be allocated up to a multiple of 128, K % 32 == 0, W readable for ceil(N/128)*128 rows.
@@ -191,8 +206,9 @@ void launch_lstm_cell(const float* G, float* c, float* h, const int32_t* lens, i
 
 // ---- head -----------------------------------------------------------------
 // per row: log-softmax over V logits, argmax (first max wins, util.cpp:63-74).  logp may be null.
+// range_flag (may be null): bit 0 is raised when a row's log-sum-exp is not finite (NaN / Inf reached the logits).
 void launch_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids,
-                              hipStream_t s);
+                              hipStream_t s, int* range_flag = nullptr);
 
 // ---- chunk-streaming pieces ----------------------------------------------
 // OnlineLfrCmvn + x*sqrt(d) + GetPosEmb (paraformer-online.cpp:196-238, 549-555, 240-268) for `n_rows`

@@ -259,6 +259,55 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
     st = upload(&m->d_predconv, q);
     if (st) return st;
     reg_scale(m->d_predconv, q.data(), q.size());
+    {
+      // The static half of the fp16-domain guard (kernels.h LaunchCtx).  Everything the two-plane kernels multiply besides the
+      // residual stream is the output of a Linear on a LayerNorm-ed row (q, k, v, the FFN hidden layer, the decoder's q / k / v,
+      // the logits' input) or an average of such rows (attention context, CIF embeddings), and a LayerNorm-ed row has norm
+      // sqrt(K) before gamma:   |LN(x) w_n + b_n| <= sqrt(K) * ||w_n o gamma||_2 + |b_n + w_n . beta|   for ANY input.
+      // A model whose bound reaches 32768 (no trained model's does: weights of norm ~1 give a few hundred) runs on the exact
+      // kernels altogether; the residual stream itself is checked per forward.
+      double worst = 0.0;
+      auto ln_linear = [&](const std::string& wn, const std::string& bn, const std::string& ln) {
+        if (!m->t.count(wn) || !m->t.count(ln + ".g")) return;
+        const Tensor& w = m->W(wn);
+        const float* bb = !bn.empty() && m->t.count(bn) ? m->W(bn).h : nullptr;
+        const float* g = m->W(ln + ".g").h; const float* be = m->W(ln + ".b").h;
+        const int N = w.shape[0], K = w.shape[1];
+        for (int n = 0; n < N; ++n) {
+          double ss = 0.0, dot = bb ? bb[n] : 0.0;
+          for (int k = 0; k < K; ++k) {
+            const double wg = (double)w.h[(size_t)n * K + k] * (double)g[k];
+            ss += wg * wg;
+            dot += (double)w.h[(size_t)n * K + k] * (double)be[k];
+          }
+          worst = std::max(worst, std::sqrt((double)K) * std::sqrt(ss) + std::fabs(dot));
+        }
+      };
+      for (int i = 0; i < c.enc_layers; ++i) {
+        const std::string ep = "enc." + std::to_string(i) + ".";
+        ln_linear(ep + "qkv.w", ep + "qkv.b", ep + "norm1");
+        ln_linear(ep + "ffn1.w", ep + "ffn1.b", ep + "norm2");
+      }
+      {
+        const float* g = m->W("enc.after_norm.g").h; const float* be = m->W("enc.after_norm.b").h;
+        double gm = 0.0, bm = 0.0;
+        for (int k = 0; k < d; ++k) { gm = std::max(gm, (double)std::fabs(g[k])); bm = std::max(bm, (double)std::fabs(be[k])); }
+        worst = std::max(worst, std::sqrt((double)d) * gm + bm);                 // |enc| (keys / values source, CIF embeddings)
+      }
+      for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string dp = "dec." + std::to_string(i) + ".";
+        ln_linear(dp + "ffn1.w", dp + "ffn1.b", dp + "norm1");
+        ln_linear(dp + "ffn2.w", "", dp + "ffn_norm");
+        ln_linear(dp + "q.w", dp + "q.b", dp + "norm3");
+        ln_linear(dp + "kv.w", dp + "kv.b", "enc.after_norm");
+      }
+      ln_linear("dec3.ffn1.w", "dec3.ffn1.b", "dec3.norm1");
+      ln_linear("dec3.ffn2.w", "", "dec3.ffn_norm");
+      ln_linear("dec.out.w", "dec.out.b", "dec.after_norm");
+      if (c.contextual) ln_linear("bias.dec.q.w", "bias.dec.q.b", "bias.dec.norm3");
+      m->static_bound = worst;
+      m->always_exact = !(worst < 32768.0);
+    }
     if (d == 4 * pfhip::kTileN) {   // LN-on-load needs the residual stream to be exactly four 128-column tiles wide
       // W' = W * gamma[k], b' = b + W beta: LayerNorm's affine part folded into the GEMM that consumes it (offline path,
       // large batches: enqueue_locked).  Products in double, rounded once.
@@ -455,6 +504,7 @@ pfhip_status build_context(pfhip_model* owner, pfhip_model** out) {
   m->t = owner->t;
   m->wscale = owner->wscale;
   m->out2_b = owner->out2_b;
+  m->static_bound = owner->static_bound; m->always_exact = owner->always_exact;
   m->wp_layer_bytes = owner->wp_layer_bytes; m->wp_off_out = owner->wp_off_out; m->wp_off_ffn1 = owner->wp_off_ffn1;
   m->wp_off_ffn2 = owner->wp_off_ffn2;
 #define X(f) m->f = owner->f;
@@ -478,8 +528,31 @@ pfhip_status read_file(const char* path, std::vector<char>& out) {
 }
 
 // ---- the forward ---------------------------------------------------------------------------------------
+// Sets the calling thread's launch context (kernels.h) for the kernels of one forward of `m`: its range-flag word and whether this
+// is the re-run on the exact kernels.
+struct ForwardCtx {
+  pfhip::LaunchCtx saved;
+  explicit ForwardCtx(pfhip_model* m) : saved(pfhip::launch_ctx()) {
+    pfhip::launch_ctx().exact = m->exact_rerun || m->always_exact;
+    pfhip::launch_ctx().range_flag = m->d_range_flag;
+  }
+  ~ForwardCtx() { pfhip::launch_ctx() = saved; }
+};
+
+pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sample_off, const int* n_samples, int B, hipStream_t s,
+                          bool feats_only);
 pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* sample_off, const int* n_samples,
                             int B, hipStream_t s, bool feats_only) {
+  m->d_range_flag = nullptr;                          // until the metadata upload places it
+  const pfhip::LaunchCtx saved = pfhip::launch_ctx();
+  pfhip::launch_ctx().exact = m->exact_rerun || m->always_exact;
+  const pfhip_status st = enqueue_body(m, d_pcm, sample_off, n_samples, B, s, feats_only);
+  pfhip::launch_ctx() = saved;
+  return st;
+}
+
+pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sample_off, const int* n_samples,
+                          int B, hipStream_t s, bool feats_only) {
   const Config& c = m->cfg;
   const int d = c.d_model, FD = m->feat_dim, FP = m->feat_pad;
   HIP_TRY(hipSetDevice(m->device));
@@ -524,8 +597,20 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
     m->m_row_len = dm + o;
     for (int b = 0; b < B; ++b) for (int t = 0; t < m->T[b]; ++t) hm[o + m->row_off[b] + t] = m->T[b];
     o += M;
+    // the forward's range flag (kernels.h LaunchCtx) is cleared by the same copy; a test may pre-raise it (pfhip_debug_poke)
+    if (o & 1) ++o;
+    hm[o] = m->debug_range_flag;
+    m->debug_range_flag = 0;
+    m->d_range_flag = dm + o;
+    pfhip::launch_ctx().range_flag = m->d_range_flag;
+    ++o;
     HIP_TRY(hipMemcpyAsync(dm, hm, o * 4, hipMemcpyHostToDevice, s));
   }
+  // what a re-run on the exact kernels needs (fetch_locked)
+  m->last_pcm = d_pcm;
+  m->last_off.assign(sample_off, sample_off + B);
+  m->last_n.assign(n_samples, n_samples + B);
+  m->last_feats_only = feats_only;
 
   // ---- workspace ---------------------------------------------------------------------------------------
   HIP_TRY(m->feats.ensure((size_t)Mp * FD * 4));
@@ -869,6 +954,7 @@ pfhip_status enqueue_locked(pfhip_model* m, const float* d_pcm, const int64_t* s
 
 // ---- a6 producer: CifPredictorV3.get_upsample_timestmap on the encoder output of the batch just run -------------------
 pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
+  ForwardCtx fc(m);
   const Config& c = m->cfg;
   if (!c.timestamp) return fail(PFHIP_ERR_UNSUPPORTED, "model has no timestamp head (us_alphas / us_cif_peak outputs)");
   if (m->have_ts) return PFHIP_OK;
@@ -969,15 +1055,46 @@ pfhip_status head_locked(pfhip_model* m, hipStream_t s, bool want_logp) {
   {
     Scope sc(m, s, K_HEAD, 0, 4.0 * m->ML * V * (want_logp ? 3 : 2));
     pfhip::launch_logsoftmax_argmax(m->logits.f(), m->vocab_pad, m->ML, V, want_logp ? m->logp.f() : nullptr,
-                                    static_cast<int32_t*>(m->ids.p), s);
+                                    static_cast<int32_t*>(m->ids.p), s, m->d_range_flag);
   }
   m->have_logp = want_logp;
   HIP_TRY(hipGetLastError());
   return PFHIP_OK;
 }
 
+// the range flag of the forward crosses to the host with the results (one 4-byte copy in front of the sync that is there anyway)
+pfhip_status read_range_flag(pfhip_model* m, hipStream_t s, bool sync) {
+  m->range_hit = 0;
+  if (!m->d_range_flag) return PFHIP_OK;
+  if (!m->h_flag) HIP_TRY(hipHostMalloc((void**)&m->h_flag, 64, hipHostMallocDefault));
+  *m->h_flag = 0;
+  HIP_TRY(hipMemcpyAsync(m->h_flag, m->d_range_flag, 4, hipMemcpyDeviceToHost, s));
+  if (sync) HIP_TRY(hipStreamSynchronize(s));
+  return PFHIP_OK;
+}
+
+pfhip_status fetch_once(pfhip_model* m, pfhip_out* out, hipStream_t s);
+// The guard of the fp16 two-plane domain (kernels.h LaunchCtx): a forward whose range flag came back raised — a LayerNorm-folded
+// row outside [2^-8, 2^12] rms, or a log-prob row that is not finite — is redone ONCE, inside the same context, on the exact
+// kernels (bf16 three-plane GEMMs and attention, fp32 operands instead of plane images), and counted
+// (pfhip_debug_poke "range_fallbacks").  The reference computes in plain fp32 (paraformer.cpp:496-541).
 pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
+  pfhip_status st = fetch_once(m, out, s);
+  if (st || !m->range_hit || m->exact_rerun || m->always_exact || !m->last_pcm || m->last_feats_only) return st;
+  ++m->range_fallbacks;
+  m->exact_rerun = true;
+  const std::vector<int64_t> off = m->last_off;
+  const std::vector<int> ns = m->last_n;
+  st = enqueue_locked(m, m->last_pcm, off.data(), ns.data(), (int)ns.size(), s, false);
+  if (!st) st = head_locked(m, s, out->logp != nullptr);
+  if (!st) st = fetch_once(m, out, s);
+  m->exact_rerun = false;
+  return st;
+}
+
+pfhip_status fetch_once(pfhip_model* m, pfhip_out* out, hipStream_t s) {
   if (!out) return fail(PFHIP_ERR_ARG, "null out");
+  ForwardCtx fc(m);
   const int B = m->B;
   for (int b = 0; b < B; ++b) {
     if (out->token_num) out->token_num[b] = m->token_num[b];
@@ -1000,7 +1117,14 @@ pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
     }
     HIP_TRY(hipStreamSynchronize(s));
   }
-  if (m->ML == 0) return PFHIP_OK;
+  if (m->ML == 0) {                                  // no token at all: NaN alphas can do that too
+    if (m->M > 0) {
+      const pfhip_status rs = read_range_flag(m, s, true);
+      if (rs) return rs;
+      m->range_hit = *m->h_flag;
+    }
+    return PFHIP_OK;
+  }
   if ((out->token_ids || out->logp) && out->max_tokens < m->maxL)
     return fail(PFHIP_ERR_CAPACITY, "max_tokens smaller than the longest token sequence");
   if (out->logp && !m->have_logp) {
@@ -1019,7 +1143,12 @@ pfhip_status fetch_locked(pfhip_model* m, pfhip_out* out, hipStream_t s) {
         HIP_TRY(hipMemcpyAsync(out->logp + (size_t)b * out->max_tokens * V, m->logp.f() + (size_t)m->tok_off[b] * V,
                                (size_t)m->n_fires[b] * V * 4, hipMemcpyDeviceToHost, s));
   }
+  {
+    const pfhip_status rs = read_range_flag(m, s, false);
+    if (rs) return rs;
+  }
   HIP_TRY(hipStreamSynchronize(s));
+  m->range_hit = m->h_flag ? *m->h_flag : 0;
   if (out->token_ids)
     for (int b = 0; b < B; ++b)
       std::memcpy(out->token_ids + (size_t)b * out->max_tokens, ids.data() + m->tok_off[b], 4 * (size_t)m->n_fires[b]);
@@ -1180,6 +1309,7 @@ void pfhip_destroy(pfhip_model* m) {
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->h_ops) (void)hipHostFree(m->h_ops);
   if (m->h_counts) (void)hipHostFree(m->h_counts);
+  if (m->h_flag) (void)hipHostFree(m->h_flag);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
@@ -1646,6 +1776,15 @@ pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
   if (std::string(what) == "blstm_flag") { m->debug_blstm_flag = value; return PFHIP_OK; }
   if (std::string(what) == "blstm_fallbacks") return (pfhip_status)m->blstm_fallbacks;      // read-out: how often the per-step form ran
   if (std::string(what) == "plane_forwards") return (pfhip_status)m->plane_forwards;        // read-out: forwards on plane-image operands
+  if (std::string(what) == "static_bound") return (pfhip_status)std::min(m->static_bound, 2.0e9);      // read-out: the load-time activation bound
+  if (std::string(what) == "always_exact") return (pfhip_status)(m->always_exact ? 1 : 0);
+  if (std::string(what) == "range_flag") { m->debug_range_flag = value; return PFHIP_OK; }    // the next forward starts with its range flag raised
+  if (std::string(what) == "range_fallbacks") {       // read-out: forwards redone on the exact kernels, over every context of the handle
+    long long n = m->range_fallbacks;
+    for (pfhip_model* cx : m->contexts) n += cx->range_fallbacks;
+    for (pfhip_model* r : m->replicas) { n += r->range_fallbacks; for (pfhip_model* cx : r->contexts) n += cx->range_fallbacks; }
+    return (pfhip_status)n;
+  }
   return fail(PFHIP_ERR_ARG, std::string("unknown debug key ") + what);
 }
 

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ y, int ldy,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, int M, int D,
-                                                        int Dout, float eps) {
+                                                        int Dout, float eps, int* range_flag) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  // NaN / Inf in the row: a later ReLU would swallow it (fmaxf(NaN, 0) = 0) and the head would see finite garbage — the
+  // forward's range flag is raised here, where every residual row passes (kernels.h LaunchCtx)
+  if (range_flag && lane == 0 && !(rstd < INFINITY)) atomicOr(range_flag, 1);
   float* yr = y + (size_t)row * ldy;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void alpha_kernel(const float* __restrict__ o,
 __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float* __restrict__ logits,
                                                                 int ldl, int ML, int V,
                                                                 float* __restrict__ logp,
-                                                                int32_t* __restrict__ ids) {
+                                                                int32_t* __restrict__ ids, int* range_flag) {
   __shared__ float s_max[4];
   __shared__ int s_idx[4];
   __shared__ float s_sum[4];
@@ -210,7 +213,10 @@ __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float* __r
   if (lane == 0) s_sum[wave] = sum;
   __syncthreads();
   const float lse = logf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
-  if (threadIdx.x == 0) ids[row] = mi;
+  if (threadIdx.x == 0) {
+    ids[row] = mi;
+    if (range_flag && !(fabsf(lse) < INFINITY)) atomicOr(range_flag, 1);      // NaN / Inf reached the logits
+  }
   if (logp) {
     float* pr = logp + (size_t)row * V;
     for (int c = threadIdx.x; c < V; c += 256) pr[c] = (lr[c] - m) - lse;
@@ -278,11 +284,11 @@ void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g
   const dim3 grid((M + 3) / 4), block(256);
   const int nv = (Dout + 255) / 256;
   if (nv <= 2)
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, y, ldy, g, b, M, D, Dout, eps);
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, y, ldy, g, b, M, D, Dout, eps, launch_ctx().range_flag);
   else if (nv <= 3)
-    hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, ldx, y, ldy, g, b, M, D, Dout, eps);
+    hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, ldx, y, ldy, g, b, M, D, Dout, eps, launch_ctx().range_flag);
   else
-    hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, y, ldy, g, b, M, D, Dout, eps);
+    hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, y, ldy, g, b, M, D, Dout, eps, launch_ctx().range_flag);
 }
 
 void launch_fsmn(const float* v, int ldv, const float* w, const float* res, int ldres, float* out,
@@ -322,9 +328,9 @@ void launch_compact(const float* stage, float* emb, const int* tok_row_src, int 
 }
 
 void launch_logsoftmax_argmax(const float* logits, int ldl, int ML, int V, float* logp, int32_t* ids,
-                              hipStream_t s) {
+                              hipStream_t s, int* range_flag) {
   if (ML <= 0) return;
-  hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3(ML), dim3(256), 0, s, logits, ldl, ML, V, logp, ids);
+  hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3(ML), dim3(256), 0, s, logits, ldl, ML, V, logp, ids, range_flag);
 }
 
 }  // namespace pfhip

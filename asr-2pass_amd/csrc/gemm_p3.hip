@@ -261,6 +261,14 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
 #undef PFHIP_SB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last (redundant) DMAs must not land in the C tile
   __syncthreads();
+#ifndef PFHIP_P3_EPI
+#define PFHIP_P3_EPI 0      // timing-only builds: 1 epilogue without its global stores, 2 no epilogue at all
+#endif
+  if (PFHIP_P3_EPI == 2) {      // keep the accumulators alive behind a condition the host never makes true
+    if (M < 0) C[tid] = acc00[0] + acc01[1] + acc10[2] + acc11[3];
+    return;
+  }
+  const bool do_store = PFHIP_P3_EPI != 1 || M < 0;
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------------------
   float* const Cs = reinterpret_cast<float*>(lds);
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
       }
       v.x += bv.x + r1v[pass].x; v.y += bv.y + r1v[pass].y; v.z += bv.z + r1v[pass].z; v.w += bv.w + r1v[pass].w;
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      if (do_store && grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
       if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
       if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
     }
@@ -345,8 +353,12 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
         uint4 hh, ll;
         split8(w8, hh, ll);
         const size_t off = image_off(ksp, grow, pc, rows_p);
-        *reinterpret_cast<uint4*>(Ph + off) = hh;
-        *reinterpret_cast<uint4*>(Pl + off) = ll;
+        if (do_store) {
+          *reinterpret_cast<uint4*>(Ph + off) = hh;
+          *reinterpret_cast<uint4*>(Pl + off) = ll;
+        } else if (hh.x == 0x12345678u && ll.y == 0x9abcdef0u) {
+          Ph[0] = 1;
+        }
       }
     }
   }

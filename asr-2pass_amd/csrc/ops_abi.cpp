@@ -93,7 +93,7 @@ int pfhip_op_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh,
   const int mp = (M + 127) / 128 * 128;
   if (M <= 0 || N <= 0 || K < 16 || K % 16 || N % 128 || rows_a % 128 || rows_w % 128 || rows_a < mp || rows_w < N || !Ah || !Al || !Wh ||
       !Wl || (!C && !Ph) || (Ph && (!Pl || rows_p % 128 || rows_p < mp)) || (C && ldc < N) || (R1 && ldr1 < N) || !(w_scale > 0.f) ||
-      (ln_stats && (!ln_colsum || ln_tiles <= 0)) || (tile_rows != 0 && tile_rows != 64 && tile_rows != 128))
+      (ln_stats && (!ln_colsum || ln_tiles <= 0)) || (tile_rows != 0 && tile_rows != 64 && tile_rows != 128 && tile_rows != 256))
     return (int)hipErrorInvalidValue;
   pfhip::launch_gemm_p3(Ah, Al, rows_a, Wh, Wl, rows_w, w_scale, C, ldc, Ph, Pl, rows_p, bias, R1, ldr1, M, N, K, relu != 0, ln_stats, ln_tiles,
                         ln_colsum, stats_out, 4, S(stream), tile_rows);

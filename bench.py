@@ -68,7 +68,7 @@ def pmc_traffic():
     WRITE_SIZE, collected with rocprofv3 in separate --pmc runs of this same command); PMC counters cannot be read from
     inside the timed run, so this is the last PROFILED value — returned with the file it came from (`traffic_source`) so
     that nobody reads it as measured in this run — or (None, None) when no file is present."""
-    for rel in ("r03/pmc_hbm_traffic.json", "r02/pmc_hbm_traffic.json", "r01/pmc_hbm_traffic_e.json", "r01/pmc_hbm_traffic_d.json", "r01/pmc_hbm_traffic_c.json",
+    for rel in ("r04/pmc_hbm_traffic.json", "r03/pmc_hbm_traffic.json", "r02/pmc_hbm_traffic.json", "r01/pmc_hbm_traffic_e.json", "r01/pmc_hbm_traffic_d.json", "r01/pmc_hbm_traffic_c.json",
                 "r01/pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", rel)) as f:
@@ -212,6 +212,55 @@ def c5_block(pkg, weights, model, n_files=8, seconds=600, workers=8):
                         f"(BASELINE.json configs[4]; the 8-GPU form shards files over replicas)",
             "xRT": n_files * seconds / dt, "wall_s": dt, "segments": int(sum(segs_of)), "tokens": int(sum(ntok)),
             "packed_forwards": int(fw), "utterances_per_forward": ut / max(1, fw), "in_flight": model.get_inflight()}
+
+
+def c3_2pass_block(pkg, weights, man, blob):
+    """BASELINE.json configs[2] AS STATED (C3): 2-pass mode — streaming encoder chunk_size = [5, 10, 5] + offline rescoring of every
+    segment the online VAD closes — through the C++ mirror of the reference's handle API (FunTpassInit / FunTpassOnlineInit /
+    FunTpassInferBuffer: onnxruntime/bin/funasr-onnx-2pass-rtf.cpp:45-175 semantics, one thread per connection like the websocket
+    handlers), Paraformer-large-sized offline + online models and the FSMN-VAD shaped so that it follows the frame energy.
+    One connection streams a 10-minute file in 600-ms messages (latency: p50 / p99 per call); 128 connections stream 60 s each
+    (throughput; every device call of a round is merged across connections).  Runs `tpass_bench` as a child process."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_pipeline import shape_vad_weights
+    exe = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "tpass_bench")
+    d = tempfile.mkdtemp(prefix="c3_2pass_")
+    out = {"workload": "2pass: online VAD + streaming Paraformer-large chunk_size=[5,10,5] + offline Paraformer-large rescoring of every "
+                       "closed segment, 600-ms messages through the FunTpassInferBuffer mirror (BASELINE.json configs[2])"}
+    try:
+        rng = np.random.default_rng(SEED_PCM + 9)
+        for name, (mm, bb) in (("asr", (man, blob)), ("online", weights.synth_weights(dict(weights.PARAFORMER_LARGE), seed=32))):
+            os.mkdir(os.path.join(d, name))
+            weights.save(os.path.join(d, name, "model.pfhip"), mm, bb)
+        os.mkdir(os.path.join(d, "vad"))
+        vman, vblob = shape_vad_weights(*weights.synth_vad_weights())
+        weights.save(os.path.join(d, "vad", "model.pfhip"), vman, vblob)
+
+        def stream_file(seconds, path):          # speech-like bursts separated by 1.2-s silences: the VAD closes a segment every few seconds
+            parts, total, i = [], 0, 0
+            while total < seconds * SR:
+                sec = [4.0, 7.5, 2.2, 11.0, 5.3][i % 5]
+                parts += [synth_pcm(2000 + i, int(sec * SR), rng), np.zeros(int(1.2 * SR), np.float32)]
+                total += len(parts[-2]) + len(parts[-1]); i += 1
+            pcm = np.concatenate(parts)[:seconds * SR]
+            np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2").tofile(path)
+        for key, seconds, conns in (("one_connection", 600, 1), ("128_connections", 60, 128)):
+            path = os.path.join(d, f"stream_{seconds}.pcm")
+            stream_file(seconds, path)
+            r = subprocess.run([exe, os.path.join(d, "asr"), os.path.join(d, "online"), os.path.join(d, "vad"), "-", path, str(conns), "2"],
+                               capture_output=True, text=True, timeout=600, env=dict(os.environ, PFHIP_WARMUP_SECONDS="10"))
+            if r.returncode != 0:
+                out[key] = {"error": (r.stderr or r.stdout)[-500:]}
+                continue
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = {"stream_seconds": seconds, "xRT": j["xrt"], "wall_s": j["wall_s"], "calls": j["calls"], "p50_call_ms": j["p50_call_ms"],
+                        "p99_call_ms": j["p99_call_ms"], "worst_call_ms": j["worst_call_ms"], "second_pass_results": j["tpass_results"]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def cpu_baseline(man, blob, utts, seconds_per_utt):
@@ -469,6 +518,11 @@ def main():
             }
         if world == 1 and not args.no_streaming:
             out["streaming"] = streaming_block(pkg, model, int(blob.nbytes), np.random.default_rng(SEED_PCM + 7))
+        if world == 1 and not args.no_streaming:
+            try:
+                out["c3_2pass"] = c3_2pass_block(pkg, weights, man, blob)
+            except Exception as e:
+                out["c3_2pass"] = {"error": str(e)}
         if world == 1 and not args.no_c4c5:
             try:
                 out["c5"] = c5_block(pkg, weights, model)

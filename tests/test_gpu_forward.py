@@ -187,9 +187,11 @@ def test_cross_request_batching_matches_separate_calls(small):
 
 
 def test_full_size_batch_matches_oracle(pkg, weights_mod):
-    """BASELINE configs[1] exactly — Paraformer-large, 32 x 30 s in one packed forward (every GEMM on the 128 x 128 tiled
-    kernel, M = 16000) — against the CPU restatement for two of the utterances: token ids identical, log-probs within the
-    1e-3 that north_star states (measured ~1e-5)."""
+    """BASELINE configs[1] exactly — Paraformer-large, 32 x 30 s in one packed forward (M = 16000: the encoder on plane-image
+    operands) — against the CPU restatement for ALL 32 utterances (oracle on a thread pool, one BLAS thread each): token ids
+    identical up to near-ties, log-probs within the 1e-3 that north_star states; the assertion message carries the maximum and the
+    95th percentile of the per-utterance log-prob error."""
+    from concurrent.futures import ThreadPoolExecutor
     cfg = dict(weights_mod.PARAFORMER_LARGE)
     man, blob = weights_mod.synth_weights(cfg)
     model = pkg.ParaformerHip().InitAsr((man, blob))
@@ -201,18 +203,31 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
     # GEMMs or the attention on another form (test_gpu_ops.py runs this test that way too)
     other_form = any(os.environ.get(k) == "0" for k in ("PFHIP_GEMM_X3", "PFHIP_GEMM_X6", "PFHIP_ATT_X3", "PFHIP_ATT_X6", "PFHIP_PLANES"))
     assert model._lib.pfhip_debug_poke(model.handle, b"plane_forwards", 0) == (0 if other_form else 1)
-    for i in (3, 31):
-        ref = P.forward_pcm(utts[i], W)
-        assert int(got["token_num"][i]) == ref["token_num"]
-        assert list(got["ids"][i]) == list(ref["ids"])
-        n = min(len(got["logp"][i]), len(ref["logp"]))
-        assert n > 50
-        err = np.abs(got["logp"][i][:n] - ref["logp"][:n]).max()
-        assert err < 1e-3, err
-        # what fp32-grade arithmetic end to end actually gives: two equally exact GPU paths (plane-image operands, fp32 operands:
-        # tools/planes_check.py) sit 1e-5 .. 1e-4 from the restatement and 8e-6 .. 5e-5 from each other over eight utterances of
-        # this batch — rounding noise amplified through 50 layers, ids identical on all 32
-        assert err < 2e-4, err
+    assert model.debug_poke("range_fallbacks") == 0 and model.debug_poke("always_exact") == 0
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:                      # noqa: BLE001 - the pool still works with threaded BLAS, only slower
+        limiter = None
+    workers = max(1, min(12, (os.cpu_count() or 4) - 2))
+    with ThreadPoolExecutor(workers) as pool:
+        refs = list(pool.map(lambda u: P.forward_pcm(u, W), utts))
+    if limiter is not None:
+        limiter.restore_original_limits()
+    errs = []
+    for i, ref in enumerate(refs):
+        assert int(got["token_num"][i]) == ref["token_num"], i
+        assert int(got["n_fires"][i]) == ref["emb"].shape[0], i
+        assert_ids_match(got["ids"][i], ref)
+        assert ref["logp"].shape[0] > 50
+        errs.append(float(np.abs(got["logp"][i] - ref["logp"]).max()))
+    errs = np.asarray(errs)
+    msg = f"log-prob error over 32 utterances: max {errs.max():.3e}, 95th percentile {np.percentile(errs, 95):.3e}, median {np.median(errs):.3e}"
+    print(msg)
+    # north_star's bound, and what fp32-grade arithmetic end to end actually gives: two equally exact GPU paths (plane-image
+    # operands, fp32 operands: tools/planes_check.py) sit 1e-5 .. 1e-4 from the restatement — rounding noise through 50 layers
+    assert errs.max() < 1e-3, msg
+    assert np.percentile(errs, 95) < 2e-4, msg
     model.close()
 
 

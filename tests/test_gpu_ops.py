@@ -394,7 +394,7 @@ def test_gemm_on_pre_split_operands(ops, M, N, K, relu):
     C1, _ = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dR1, relu=relu, want_c=True, want_planes=False)
     assert np.array_equal(C1.cpu().numpy()[:M], C.cpu().numpy()[:M])
     # both tile heights (64 x 128: three workgroups per CU for small grids; 128 x 128), every output form: bit-identical
-    for tr in (64, 128):
+    for tr in (64, 128, 256):
         Ct, Pt = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dR1, relu=relu, want_c=True, want_planes=True, tile_rows=tr)
         assert np.array_equal(Ct.cpu().numpy()[:M], C.cpu().numpy()[:M]), tr
         assert np.array_equal(ops.planes_to_float(Pt[0], Pt[1], Pt[2], N)[:M], pl), tr

@@ -100,8 +100,9 @@ void ParaformerHip::LoadOffline(const std::string& am_model, const std::string& 
     std::fprintf(stderr, "ParaformerHip: %s holds no hotword embedder (bias_embed / bias_encoder): hotwords are ignored\n", hw_model_.c_str());
   // What the decoder threads get, whatever --model-thread-num says: their concurrent Forward calls are merged into packed
   // launches (a lone caller never waits: pfhip_set_batching) and dealt to PFHIP_INFLIGHT execution contexts over the one weight set.
-  // A model with the timestamp head keeps ONE context unless told otherwise (see DESIGN §6 / the BLSTM notes).
-  const int inflight = Knob("PFHIP_INFLIGHT", pfhip_has_timestamp_head(handle_) ? 1 : 3);
+  // (Round 3 kept ONE context for models with the timestamp head: their persistent recurrence held a host lock to the end of the
+  // caller's stream.  The recurrences of a device now queue on one stream of their own and the lock covers the enqueue only.)
+  const int inflight = Knob("PFHIP_INFLIGHT", 3);
   if (inflight > 1 && pfhip_set_inflight(handle_, inflight) != PFHIP_OK)
     std::fprintf(stderr, "ParaformerHip::InitAsr: %s (one forward at a time)\n", pfhip_last_error());
   const int wait_us = Knob("PFHIP_OFFLINE_WAIT_US", 3000);     // 0 = no merging

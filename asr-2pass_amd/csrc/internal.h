@@ -176,6 +176,9 @@ struct pfhip_model {
   Buf ts_up, ts_gx, ts_y, ts_hx, ts_a2, ts_alphas, ts_peaks, ts_meta, ts_cst;
   bool have_ts = false;
   int debug_blstm_flag = 0;        // pfhip_debug_poke
+  hipStream_t blstm_stream = nullptr;      // per DEVICE (on the weight owner): every context's persistent recurrence runs here, in turn
+  hipEvent_t ev_ts_in = nullptr, ev_ts_out = nullptr;
+  bool ts_persistent = false;              // the last timestamp head ran the persistent kernel: its error word is read with the results
   int blstm_fallbacks = 0;         // timestamp requests served by the per-step recurrence after a barrier time-out
   float out2_b = 0.f;
   int n_hw = 0;                  // hotword embeddings resident in `hw` ([n_hw, d])

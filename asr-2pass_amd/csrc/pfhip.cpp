@@ -953,7 +953,7 @@ pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sam
 }
 
 // ---- a6 producer: CifPredictorV3.get_upsample_timestmap on the encoder output of the batch just run -------------------
-pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
+pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s, bool stepwise_only = false) {
   ForwardCtx fc(m);
   const Config& c = m->cfg;
   if (!c.timestamp) return fail(PFHIP_ERR_UNSUPPORTED, "model has no timestamp head (us_alphas / us_cif_peak outputs)");
@@ -1003,39 +1003,48 @@ pfhip_status ts_head_locked(pfhip_model* m, hipStream_t s) {
     // CUs there — the request is NOT failed: the same recurrence is redone as one launch per step (blstm.hip), which needs no
     // co-residency and gives the same values bit for bit.  PFHIP_BLSTM_STEPWISE=1 skips the persistent attempt.
     static const bool force_stepwise = [] { const char* e = getenv("PFHIP_BLSTM_STEPWISE"); return e && e[0] == '1'; }();
-    auto recurrence = [&](bool stepwise) -> pfhip_status {
+    auto recurrence = [&](bool stepwise, hipStream_t rs) -> pfhip_status {
       for (int b0 = 0; b0 < B; b0 += 32) {
         const int nb = std::min(32, B - b0);
         int lmax = 0;
         for (int b = b0; b < b0 + nb; ++b) lmax = std::max(lmax, 3 * m->T[b]);
         if (stepwise)
           HIP_TRY(pfhip::launch_blstm_stepwise(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), m->ts_cst.f(), d_off + b0, d_len + b0, nb,
-                                               lmax, s));
+                                               lmax, rs));
         else
-          HIP_TRY(pfhip::launch_blstm(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), d_off + b0, d_len + b0, nb, lmax, s));
+          HIP_TRY(pfhip::launch_blstm(m->ts_gx.f(), m->d_whh, m->ts_y.f(), m->ts_hx.f(), d_off + b0, d_len + b0, nb, lmax, rs));
       }
       return PFHIP_OK;
     };
     HIP_TRY(m->ts_cst.ensure((size_t)2 * 32 * 512 * 4));
-    bool stepwise = force_stepwise;
-    if (!stepwise) {
-      // the persistent kernel wants the 32 blocks of a direction co-resident on one XCD: two contexts of a device must not run
-      // it at the same time (they would time each other out into the per-step form) — one at a time per device
+    m->ts_persistent = false;
+    if (!stepwise_only && !force_stepwise) {
+      // The persistent kernel wants the 32 blocks of a direction co-resident on one XCD: two contexts of a device must not run it
+      // at the same time (they would time each other out into the per-step form).  Round 3 held a host lock from the launch to the
+      // end of the stream — the whole rest of the caller's forward — so the contexts of a timestamp model took turns and three
+      // batches in flight were slower than one (bench.c4: 58 ms against 38).  Now every context of a device enqueues its recurrence
+      // on ONE stream of that device (events tie it to the caller's stream), so the device orders them and the lock covers the
+      // enqueue only; the kernel's error word travels to the host with the results (fetch_once), and a raised one redoes the
+      // recurrence per step there.
+      pfhip_model* owner = m->weights_of ? m->weights_of : m;
       static std::mutex blstm_mu[64];
-      std::lock_guard<std::mutex> bl(blstm_mu[m->device & 63]);
-      pfhip_status st = recurrence(false);
-      if (st) return st;
-      unsigned flag = 0;
-      HIP_TRY(hipMemcpyAsync(&flag, m->ts_hx.f() + pfhip::kBlstmFlagWord, 4, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (flag) {
-        HIP_TRY(hipMemsetAsync(m->ts_hx.f() + pfhip::kBlstmFlagWord, 0, 4, s));
-        ++m->blstm_fallbacks;
-        stepwise = true;
+      {
+        std::lock_guard<std::mutex> bl(blstm_mu[m->device & 63]);
+        if (!owner->blstm_stream) HIP_TRY(hipStreamCreateWithFlags(&owner->blstm_stream, hipStreamNonBlocking));
+        if (!m->ev_ts_in) {
+          HIP_TRY(hipEventCreateWithFlags(&m->ev_ts_in, hipEventDisableTiming));
+          HIP_TRY(hipEventCreateWithFlags(&m->ev_ts_out, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(m->ev_ts_in, s));
+        HIP_TRY(hipStreamWaitEvent(owner->blstm_stream, m->ev_ts_in, 0));
+        pfhip_status st = recurrence(false, owner->blstm_stream);
+        if (st) return st;
+        HIP_TRY(hipEventRecord(m->ev_ts_out, owner->blstm_stream));
       }
-    }
-    if (stepwise) {
-      pfhip_status st = recurrence(true);
+      HIP_TRY(hipStreamWaitEvent(s, m->ev_ts_out, 0));
+      m->ts_persistent = true;
+    } else {
+      pfhip_status st = recurrence(true, s);
       if (st) return st;
     }
     pfhip::launch_alpha2(m->ts_y.f(), 2 * d, m->W("pred.out2.w").d, m->out2_b, c.smooth_factor2, c.noise_threshold2,
@@ -1102,20 +1111,30 @@ pfhip_status fetch_once(pfhip_model* m, pfhip_out* out, hipStream_t s) {
     if (out->n_frames) out->n_frames[b] = m->T[b];
   }
   if (out->us_alphas || out->us_peaks || out->us_len) {
-    pfhip_status st = ts_head_locked(m, s);
-    if (st) return st;
-    for (int b = 0; b < B; ++b) {
-      const int L = 3 * m->T[b];
-      if (out->us_len) out->us_len[b] = L;
-      if ((out->us_alphas || out->us_peaks) && out->max_us < L) return fail(PFHIP_ERR_CAPACITY, "max_us smaller than 3 x frames");
-      if (out->us_alphas && L)
-        HIP_TRY(hipMemcpyAsync(out->us_alphas + (size_t)b * out->max_us, m->ts_alphas.f() + (size_t)3 * m->row_off[b], (size_t)L * 4,
-                               hipMemcpyDeviceToHost, s));
-      if (out->us_peaks && L)
-        HIP_TRY(hipMemcpyAsync(out->us_peaks + (size_t)b * out->max_us, m->ts_peaks.f() + (size_t)3 * m->row_off[b], (size_t)L * 4,
-                               hipMemcpyDeviceToHost, s));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      pfhip_status st = ts_head_locked(m, s, attempt == 1);
+      if (st) return st;
+      for (int b = 0; b < B; ++b) {
+        const int L = 3 * m->T[b];
+        if (out->us_len) out->us_len[b] = L;
+        if ((out->us_alphas || out->us_peaks) && out->max_us < L) return fail(PFHIP_ERR_CAPACITY, "max_us smaller than 3 x frames");
+        if (out->us_alphas && L)
+          HIP_TRY(hipMemcpyAsync(out->us_alphas + (size_t)b * out->max_us, m->ts_alphas.f() + (size_t)3 * m->row_off[b], (size_t)L * 4,
+                                 hipMemcpyDeviceToHost, s));
+        if (out->us_peaks && L)
+          HIP_TRY(hipMemcpyAsync(out->us_peaks + (size_t)b * out->max_us, m->ts_peaks.f() + (size_t)3 * m->row_off[b], (size_t)L * 4,
+                                 hipMemcpyDeviceToHost, s));
+      }
+      // the persistent recurrence's error word (a step barrier that timed out: its 32 blocks were not co-resident) comes back with
+      // the results; raised, the request is NOT failed: the same recurrence is redone as one launch per step, bit for bit the same
+      unsigned flag = 0;
+      if (m->ts_persistent && m->M > 0) HIP_TRY(hipMemcpyAsync(&flag, m->ts_hx.f() + pfhip::kBlstmFlagWord, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (!flag) break;
+      HIP_TRY(hipMemsetAsync(m->ts_hx.f() + pfhip::kBlstmFlagWord, 0, 4, s));
+      ++m->blstm_fallbacks;
+      m->have_ts = false;
     }
-    HIP_TRY(hipStreamSynchronize(s));
   }
   if (m->ML == 0) {                                  // no token at all: NaN alphas can do that too
     if (m->M > 0) {
@@ -1314,6 +1333,9 @@ void pfhip_destroy(pfhip_model* m) {
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
   if (m->ev_enc_ready) (void)hipEventDestroy(m->ev_enc_ready);
+  if (m->ev_ts_in) (void)hipEventDestroy(m->ev_ts_in);
+  if (m->ev_ts_out) (void)hipEventDestroy(m->ev_ts_out);
+  if (m->blstm_stream) (void)hipStreamDestroy(m->blstm_stream);
   for (hipEvent_t e : m->ev_kv) if (e) (void)hipEventDestroy(e);
   delete m;
 }

@@ -1796,7 +1796,12 @@ pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
   if (!m || !what) return fail(PFHIP_ERR_ARG, "bad argument");
   std::lock_guard<std::mutex> lk(m->mu);
   if (std::string(what) == "blstm_flag") { m->debug_blstm_flag = value; return PFHIP_OK; }
-  if (std::string(what) == "blstm_fallbacks") return (pfhip_status)m->blstm_fallbacks;      // read-out: how often the per-step form ran
+  if (std::string(what) == "blstm_fallbacks") {     // read-out: how often the per-step form ran, over every context of the handle
+    long long n = m->blstm_fallbacks;
+    for (pfhip_model* cx : m->contexts) n += cx->blstm_fallbacks;
+    for (pfhip_model* r : m->replicas) { n += r->blstm_fallbacks; for (pfhip_model* cx : r->contexts) n += cx->blstm_fallbacks; }
+    return (pfhip_status)n;
+  }
   if (std::string(what) == "plane_forwards") return (pfhip_status)m->plane_forwards;        // read-out: forwards on plane-image operands
   if (std::string(what) == "static_bound") return (pfhip_status)std::min(m->static_bound, 2.0e9);      // read-out: the load-time activation bound
   if (std::string(what) == "always_exact") return (pfhip_status)(m->always_exact ? 1 : 0);

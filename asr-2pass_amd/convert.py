@@ -161,6 +161,12 @@ def punc_name_map(cfg):
     return m
 
 
+def _without_model_components(key):
+    """FunASR's export wrappers keep the original module under `.model` (encoder.model.encoders0.0...): the key with every
+    `model` path component dropped (the C++ reader does the same, csrc/model_files.cpp)."""
+    return ".".join(p for p in key.split(".") if p != "model")
+
+
 def _fill(specs, name_map, state, extra):
     """specs: [(name, shape, init)]; returns (manifest tensors, blob); a tensor is taken from `extra`, else from the
     state_dict through name_map, reshaped when only singleton dims differ ([d,1,k] -> [d,k])."""
@@ -170,6 +176,10 @@ def _fill(specs, name_map, state, extra):
         off += (int(np.prod(shape)) * 4 + Wt.ALIGN - 1) // Wt.ALIGN * Wt.ALIGN
     blob = np.zeros(off // 4, np.float32)
     missing = []
+    state = dict(state)
+    for k in list(state):
+        state.setdefault(_without_model_components(k), state[k])
+    used = set()
     for name, shape, _ in specs:
         if name in extra:
             arr = np.asarray(extra[name], np.float32)
@@ -179,6 +189,7 @@ def _fill(specs, name_map, state, extra):
                 missing.append(f"{name} <- {key}")
                 continue
             t = state[key]
+            used.add(key)
             arr = t.detach().cpu().float().numpy() if hasattr(t, "detach") else np.asarray(t, np.float32)
         if list(arr.shape) != list(shape):
             if arr.size != int(np.prod(shape)) or [d for d in arr.shape if d != 1] != [d for d in shape if d != 1]:
@@ -187,7 +198,9 @@ def _fill(specs, name_map, state, extra):
         o = tensors[name]["offset"] // 4
         blob[o:o + arr.size] = arr.reshape(-1)
     if missing:
-        raise KeyError("checkpoint lacks: " + "; ".join(missing[:8]) + (" ..." if len(missing) > 8 else ""))
+        near = [k for k in state if k not in used and _without_model_components(k) not in used][:8]
+        raise KeyError("checkpoint lacks: " + "; ".join(missing[:8]) + (" ..." if len(missing) > 8 else "") +
+                       (f"  (unmatched keys in the checkpoint: {', '.join(near)})" if near else ""))
     return tensors, blob, off
 
 

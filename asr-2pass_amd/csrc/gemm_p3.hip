@@ -796,6 +796,9 @@ void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K
                      static_cast<unsigned char*>(hi), static_cast<unsigned char*>(lo));
 }
 
+#ifndef PFHIP_P3_LDS_PAD
+#define PFHIP_P3_LDS_PAD 0      // timing-only builds: extra LDS per workgroup of the 128-row kernel (32768: ONE workgroup per CU)
+#endif
 void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                     void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
                     const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s, int tile_rows) {
@@ -835,7 +838,7 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
       launch_with_lds<gemm_p3_64_kernel<LNF, OUTM>>(n_tiles, kHLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
     else                                                                                                                        \
-      launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+      launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds + PFHIP_P3_LDS_PAD, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
                                                      M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
   }
   if (ln_stats) {

@@ -156,6 +156,8 @@ def _tensor(buf) -> Tuple[str, Optional[np.ndarray], int, bool]:
         return name, None, dtype, True
     if dtype not in _DTYPES:
         if dtype == 16 and raw is not None:                   # bfloat16: widen to float32
+            if len(raw) != n * 2:
+                raise OnnxFormatError(f"tensor {name}: raw_data holds {len(raw)} bytes, dims {dims} need {n * 2}")
             u = np.frombuffer(raw, dtype="<u2").astype(np.uint32) << 16
             return name, u.view(np.float32).reshape(dims), dtype, False
         raise OnnxFormatError(f"tensor {name}: unsupported data type {DTYPE_NAMES.get(dtype, dtype)}")
@@ -169,15 +171,21 @@ def _tensor(buf) -> Tuple[str, Optional[np.ndarray], int, bool]:
     elif f64:
         arr = np.frombuffer(b"".join(f64), dtype="<f8")
     elif typed:
-        if dtype == 10:                                       # float16 travels as its bit pattern in int32_data
-            arr = np.asarray(typed, np.uint16).view(np.float16)
-        else:
-            arr = np.asarray(typed).astype(np_dt)
+        try:
+            if dtype == 10:                                   # float16 travels as its bit pattern in int32_data
+                arr = (np.asarray(typed, np.int64) & 0xFFFF).astype(np.uint16).view(np.float16)
+            else:
+                arr = np.asarray(typed, np.int64 if np_dt.kind in "iub" else np.float64).astype(np_dt)
+        except (OverflowError, ValueError) as e:
+            raise OnnxFormatError(f"tensor {name}: {e}") from None
     else:
         arr = np.zeros(0, np_dt)
     if arr.size != n:
         raise OnnxFormatError(f"tensor {name}: {arr.size} values for dims {dims}")
-    return name, arr.reshape(dims), dtype, False
+    try:
+        return name, arr.reshape(dims), dtype, False
+    except ValueError as e:
+        raise OnnxFormatError(f"tensor {name}: {e}") from None
 
 
 def _attribute(buf):

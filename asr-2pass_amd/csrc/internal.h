@@ -152,6 +152,11 @@ struct pfhip_model {
   std::vector<int> last_n;
   int plane_forwards = 0;                                       // forwards of this context that took the plane path (debug read-out)
   Buf ctxP, xP, hP;                                             // activation plane images of a large batch: context, residual stream, FFN hidden
+  Buf encP, xdP;                                                // decoder on plane operands: images of the encoder output and of the token-side residual stream
+  // fp16 plane images of the decoder's large weights per layer (dec3 = the last entry: FFN only): [layer] { ffn1' | ffn2' | kv | out }
+  unsigned char* d_dwplanes = nullptr;
+  size_t dwp_layer_bytes = 0, dwp_off_ffn2 = 0, dwp_off_kv = 0, dwp_off_out = 0;
+  int dec_plane_forwards = 0;                                   // forwards whose decoder took the plane path (debug read-out)
   // the same for the decoder's FFN: ffn1 with norm1, ffn2 with ffn_norm; [dec_layers + 1] entries (the last one is dec3)
   float* d_dlnw1 = nullptr; float* d_dlnb1 = nullptr; float* d_dlns1 = nullptr;
   float* d_dlnw2 = nullptr; float* d_dlnb2 = nullptr; float* d_dlns2 = nullptr;

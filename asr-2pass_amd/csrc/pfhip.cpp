@@ -408,6 +408,34 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
           reg_scale(m->d_dlnw2 + (size_t)i * d * f, &w2[(size_t)i * d * f], (size_t)d * f);
           reg_scale(m->d_dlnw3 + (size_t)i * d * d, &w3[(size_t)i * d * d], (size_t)d * d);
         }
+        // Round 4: the decoder's large weights as plane images too (gemm_p3.hip; +0.2 GB for Paraformer-large): FFN1' / FFN2' with
+        // their LayerNorms folded in, the K/V projection of the encoder output and the output projection of the cross-attention
+        if (m->wp_layer_bytes != 0) {
+          const size_t j1 = 2 * pfhip::plane_image_bytes(f, d), j2 = 2 * pfhip::plane_image_bytes(d, f);
+          const size_t jk = 2 * pfhip::plane_image_bytes(2 * d, d), jo = 2 * pfhip::plane_image_bytes(d, d);
+          m->dwp_off_ffn2 = j1; m->dwp_off_kv = j1 + j2; m->dwp_off_out = j1 + j2 + jk;
+          const size_t per = j1 + j2 + jk + jo;
+          if (hipMalloc((void**)&m->d_dwplanes, per * (size_t)DL) != hipSuccess) { (void)hipGetLastError(); m->d_dwplanes = nullptr; }
+          for (int i = 0; i < DL && m->d_dwplanes; ++i) {
+            unsigned char* base = m->d_dwplanes + per * (size_t)i;
+            const float* wf1 = m->d_dlnw1 + (size_t)i * f * d;
+            const float* wf2 = m->d_dlnw2 + (size_t)i * d * f;
+            pfhip::launch_split_planes(wf1, d, f, f, d, m->w_scale_of(wf1), base, base + j1 / 2, nullptr);
+            pfhip::launch_split_planes(wf2, f, d, d, f, m->w_scale_of(wf2), base + m->dwp_off_ffn2, base + m->dwp_off_ffn2 + j2 / 2, nullptr);
+            if (i < c.dec_layers) {
+              const std::string dp = "dec." + std::to_string(i) + ".";
+              const float* wkv = m->W(dp + "kv.w").d;
+              const float* wo = m->W(dp + "out.w").d;
+              pfhip::launch_split_planes(wkv, d, 2 * d, 2 * d, d, m->w_scale_of(wkv), base + m->dwp_off_kv, base + m->dwp_off_kv + jk / 2, nullptr);
+              pfhip::launch_split_planes(wo, d, d, d, d, m->w_scale_of(wo), base + m->dwp_off_out, base + m->dwp_off_out + jo / 2, nullptr);
+            }
+          }
+          if (m->d_dwplanes) {
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            m->dwp_layer_bytes = per;
+          }
+        }
       }
       if (st) return st;
     }
@@ -487,7 +515,7 @@ pfhip_status build_model(const void* blob, size_t blob_bytes, const char* manife
   X(d_blob) X(d_w0qkv) X(d_predconv) X(d_vocab_bias) X(d_kv_all_w) X(d_kv_all_b) X(d_lnw_qkv) X(d_lnb_qkv) X(d_lnw_ffn1)     \
   X(d_lnb_ffn1) X(d_lns_qkv) X(d_lns_ffn1) X(d_dlnw1) X(d_dlnb1) X(d_dlns1) X(d_dlnw2) X(d_dlnb2) X(d_dlns2) X(d_dlnw3)        \
   X(d_dlnb3) X(d_dlns3) X(d_up_w) X(d_up_b) X(d_wih) X(d_bih) X(d_whh) X(d_window) X(d_tw) X(d_mel_off) X(d_mel_size)         \
-  X(d_mel_w) X(d_inv_ts) X(d_wplanes)
+  X(d_mel_w) X(d_inv_ts) X(d_wplanes) X(d_dwplanes)
 
 pfhip_status create_streams(pfhip_model* m) {
   HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
@@ -513,6 +541,8 @@ pfhip_status build_context(pfhip_model* owner, pfhip_model** out) {
   m->static_bound = owner->static_bound; m->always_exact = owner->always_exact;
   m->wp_layer_bytes = owner->wp_layer_bytes; m->wp_off_out = owner->wp_off_out; m->wp_off_ffn1 = owner->wp_off_ffn1;
   m->wp_off_ffn2 = owner->wp_off_ffn2;
+  m->dwp_layer_bytes = owner->dwp_layer_bytes; m->dwp_off_ffn2 = owner->dwp_off_ffn2; m->dwp_off_kv = owner->dwp_off_kv;
+  m->dwp_off_out = owner->dwp_off_out;
 #define X(f) m->f = owner->f;
   PFHIP_WEIGHT_PTRS(X)
 #undef X
@@ -877,7 +907,59 @@ pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sam
                                  m->w_scale_of(Wd));
   };
   bool xd_has_stats = false;          // lnstats holds the row statistics of the current xd
+  // Round 4: from 3500 token rows on (and only where the encoder ran on plane images: same arithmetic form) the decoder's large
+  // GEMMs take plane-image operands as well (gemm_p3.hip): the K/V projection reads the images of the encoder output (one split
+  // launch per forward), the cross-attention writes its context as images, the output projection leaves the token-side residual
+  // stream as fp32 + images + row statistics, FFN1' (norm1 folded) reads those and leaves the hidden activation as fp32 + images +
+  // the 16 statistics pairs per row that FFN2' (ffn_norm folded) merges.  The first layer's FFN (its input comes from the CIF),
+  // the q projections (their input comes from the FSMN kernel), a contextual model's last layer and the vocabulary projection stay
+  // on the in-loop-split kernels.
+  static const int dec_planes_min_rows = [] { const char* e = getenv("PFHIP_DEC_PLANES_MIN_ROWS"); return e && *e ? atoi(e) : 3500; }();
+  const bool dec_planes = planes && fuse_dec && m->dwp_layer_bytes != 0 && ML >= dec_planes_min_rows && pfhip::attention_planes_ok(m->maxL) &&
+                          pfhip::gemm_f16_planes_form();
+  Img encP{nullptr, nullptr}, xdP{nullptr, nullptr}, hdP{nullptr, nullptr}, ctxdP{nullptr, nullptr};
+  bool xd_has_planes = false;
+  if (dec_planes) {
+    ++m->dec_plane_forwards;
+    const size_t pe = pfhip::plane_image_bytes(Mp, d), pdd = pfhip::plane_image_bytes(MLp, d), pff = pfhip::plane_image_bytes(MLp, c.dec_ffn);
+    HIP_TRY(m->encP.ensure(2 * pe));
+    HIP_TRY(m->xdP.ensure(2 * pdd));
+    HIP_TRY(m->ctxP.ensure(2 * pdd));
+    HIP_TRY(m->hP.ensure(2 * pff));
+    encP = {static_cast<unsigned char*>(m->encP.p), static_cast<unsigned char*>(m->encP.p) + pe};
+    xdP = {static_cast<unsigned char*>(m->xdP.p), static_cast<unsigned char*>(m->xdP.p) + pdd};
+    ctxdP = {static_cast<unsigned char*>(m->ctxP.p), static_cast<unsigned char*>(m->ctxP.p) + pdd};
+    hdP = {static_cast<unsigned char*>(m->hP.p), static_cast<unsigned char*>(m->hP.p) + pff};
+    Scope sc(m, s, K_OTHER, 0, 8.0 * M * d);
+    pfhip::launch_split_planes(m->enc.f(), d, M, Mp, d, 1.0f, encP.hi, encP.lo, s);
+  }
+  auto dwimg = [&](int layer, int which) -> WImg {         // 0 ffn1', 1 ffn2', 2 kv, 3 out
+    const unsigned char* base = m->d_dwplanes + m->dwp_layer_bytes * (size_t)layer;
+    const std::string dp = "dec." + std::to_string(layer) + ".";
+    switch (which) {
+      case 0: return {base, base + pfhip::plane_image_bytes(c.dec_ffn, d), m->w_scale_of(m->d_dlnw1 + (size_t)layer * c.dec_ffn * d)};
+      case 1: return {base + m->dwp_off_ffn2, base + m->dwp_off_ffn2 + pfhip::plane_image_bytes(d, c.dec_ffn),
+                      m->w_scale_of(m->d_dlnw2 + (size_t)layer * d * c.dec_ffn)};
+      case 2: return {base + m->dwp_off_kv, base + m->dwp_off_kv + pfhip::plane_image_bytes(2 * d, d), m->w_scale_of(m->W(dp + "kv.w").d)};
+      default: return {base + m->dwp_off_out, base + m->dwp_off_out + pfhip::plane_image_bytes(d, d), m->w_scale_of(m->W(dp + "out.w").d)};
+    }
+  };
+  // one gemm_p3 launch over `rows` rows: A image with rows_a rows per K-step, result as fp32 (Cd) and / or images (P, MLp rows)
+  auto dgemm_pl = [&](const Img& A, int rows_a, const WImg& W, int rows, int N, int K, float* Cd, int ldc, const Img* P, const float* bias,
+                      const float* R1, bool relu, const float* st_in, int tiles_in, const float* colsum, float* st_out) {
+    Scope sc(m, s, K_GEMM, 2.0 * rows * (double)N * K, 4.0 * ((double)rows * K + (double)N * K + (double)rows * N));
+    pfhip::launch_gemm_p3(A.hi, A.lo, rows_a, W.hi, W.lo, N, W.scale, Cd, ldc, P ? P->hi : nullptr, P ? P->lo : nullptr, MLp, bias, R1, d, rows, N, K,
+                          relu, st_in, tiles_in, colsum, st_out, 4, s);
+  };
   auto dec_ffn = [&](const std::string& p, int li, const float* xin, float* out) {
+    if (dec_planes && xd_has_planes && xd_has_stats) {
+      // FFN1' on the images of the residual stream: hidden activation as fp32 (row statistics ride on that pass) + images
+      dgemm_pl(xdP, MLp, dwimg(li, 0), ML, c.dec_ffn, d, m->hd.f(), c.dec_ffn, &hdP, m->d_dlnb1 + (size_t)li * c.dec_ffn, nullptr, true,
+               m->lnstats.f(), 4, m->d_dlns1 + (size_t)li * c.dec_ffn, m->lnstats2.f());
+      dgemm_pl(hdP, MLp, dwimg(li, 1), ML, d, c.dec_ffn, out, d, nullptr, m->d_dlnb2 + (size_t)li * d, nullptr, false, m->lnstats2.f(), ftiles,
+               m->d_dlns2 + (size_t)li * d, nullptr);
+      return;
+    }
     if (fuse_dec) {
       if (xd_has_stats) {
         x6ln(xin, d, m->d_dlnw1 + (size_t)li * c.dec_ffn * d, c.dec_ffn, m->hd.f(), m->d_dlnb1 + (size_t)li * c.dec_ffn, nullptr, true,
@@ -908,19 +990,37 @@ pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sam
     }
     lnorm(m, s, xd, d, m->yd.f(), d, p + "norm3", ML, d, d);
     gemm(m, s, m->yd.f(), d, m->W(p + "q.w").d, d, d, d, m->qd.f(), d, m->W(p + "q.b").d, nullptr, 0, nullptr, 0, ML, false);
+    const bool plain_layer = !(c.contextual && i == c.dec_layers - 1);
     if (side_kv) {
       kvbuf = m->kvside.f() + (size_t)i * Mp * 2 * d;
       HIP_TRY(hipStreamWaitEvent(s, m->ev_kv[(size_t)i], 0));
+    } else if (dec_planes) {
+      Scope sc(m, s, K_GEMM, 2.0 * M * 2.0 * d * d, 4.0 * ((double)M * d + 2.0 * d * d + 2.0 * M * d));
+      const WImg W = dwimg(i, 2);
+      pfhip::launch_gemm_p3(encP.hi, encP.lo, Mp, W.hi, W.lo, 2 * d, W.scale, kvbuf, 2 * d, nullptr, nullptr, Mp, m->W(p + "kv.b").d, nullptr, 0, M,
+                            2 * d, d, false, nullptr, 0, nullptr, nullptr, 4, s);
     } else {
       gemm(m, s, m->enc.f(), d, m->W(p + "kv.w").d, 2 * d, d, d, kvbuf, 2 * d, m->W(p + "kv.b").d, nullptr, 0, nullptr, 0, M,
            false);
     }
     {
       Scope sc(m, s, K_ATTN, 4.0 * cross_pairs * d, 8.0 * ML * d + 8.0 * M * d);
-      pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
-                              m->m_row_off, m->m_len, B, c.n_head, m->maxL, att_scale, s);
+      if (dec_planes && plain_layer)     // the context leaves as plane images for the output projection; no fp32 context is written
+        pfhip::launch_attention_x3(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len, m->m_row_off, m->m_len,
+                                   B, c.n_head, m->maxL, att_scale, s, nullptr, nullptr, 0, false, ctxdP.hi, ctxdP.lo, MLp);
+      else
+        pfhip::launch_attention(m->qd.f(), d, kvbuf, 2 * d, kvbuf + d, 2 * d, m->ctxd.f(), d, m->m_tok_off, m->m_tok_len,
+                                m->m_row_off, m->m_len, B, c.n_head, m->maxL, att_scale, s);
     }
     xd_has_stats = false;
+    xd_has_planes = false;
+    if (dec_planes && plain_layer) {
+      // xd = ctx Wo^T + b + xd: fp32 for the residual adds, images + row statistics for the next FFN1'
+      dgemm_pl(ctxdP, MLp, dwimg(i, 3), ML, d, d, xd, d, &xdP, m->W(p + "out.b").d, xd, false, nullptr, 0, nullptr, m->lnstats.f());
+      xd_has_stats = true;
+      xd_has_planes = true;
+      continue;
+    }
     if (!(c.contextual && i == c.dec_layers - 1)) {
       if (fuse_dec) {          // the output projection also leaves the statistics the next norm1 needs
         x6ln(m->ctxd.f(), d, m->W(p + "out.w").d, d, xd, m->W(p + "out.b").d, xd, false, nullptr, 0, nullptr, m->lnstats.f());
@@ -1325,7 +1425,7 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst, &m->ctxP, &m->xP, &m->hP})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst, &m->ctxP, &m->xP, &m->hP, &m->encP, &m->xdP})
     b->release();
   if (!m->weights_of) {          // a context borrows these
 #define X(f) if (m->f) (void)hipFree((void*)m->f);
@@ -1811,6 +1911,7 @@ pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
     return (pfhip_status)n;
   }
   if (std::string(what) == "plane_forwards") return (pfhip_status)m->plane_forwards;        // read-out: forwards on plane-image operands
+  if (std::string(what) == "dec_plane_forwards") return (pfhip_status)m->dec_plane_forwards; // ... whose decoder took the plane path too
   if (std::string(what) == "static_bound") return (pfhip_status)std::min(m->static_bound, 2.0e9);      // read-out: the load-time activation bound
   if (std::string(what) == "always_exact") return (pfhip_status)(m->always_exact ? 1 : 0);
   if (std::string(what) == "range_flag") { m->debug_range_flag = value; return PFHIP_OK; }    // the next forward starts with its range flag raised

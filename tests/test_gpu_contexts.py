@@ -247,16 +247,17 @@ def test_sixteen_decoder_threads_behind_the_default_server_flags(pkg, weights_mo
     assert out0.returncode == 0, out0.stderr[-2000:]
     r0 = json.loads(out0.stdout.strip().splitlines()[-1])
     assert r0["inflight"] == 1 and r0["concurrent"]["forwards"] == r0["concurrent"]["utterances"] == 24 and r0["mismatches"] == 0
-    # a model with the timestamp head: ONE context by default (its persistent BLSTM kernel stalls the others), still merged;
+    # a model with the timestamp head: three contexts by default too since round 4 (the persistent BLSTM recurrences of a device
+    # queue on one stream of their own instead of holding a host lock to the end of the caller's stream), still merged;
     # PFHIP_INFLIGHT overrides
     tdir = model_dir("asr_ts", 1)
     outt = subprocess.run([exe, str(tdir), "-", "16", "48", "2", "9", "1"], capture_output=True, text=True, timeout=600, env=env)
     assert outt.returncode == 0, outt.stderr[-2000:]
     rt = json.loads(outt.stdout.strip().splitlines()[-1])
-    assert rt["mismatches"] == 0 and rt["near_tie_flips"] <= 1 and rt["failures"] == 0 and rt["inflight"] == 1
+    assert rt["mismatches"] == 0 and rt["near_tie_flips"] <= 1 and rt["failures"] == 0 and rt["inflight"] == 3
     assert rt["concurrent"]["forwards"] < rt["concurrent"]["utterances"]
     outt3 = subprocess.run([exe, str(tdir), "-", "16", "48", "2", "9", "1"], capture_output=True, text=True, timeout=600,
-                           env=dict(env, PFHIP_INFLIGHT="3"))
+                           env=dict(env, PFHIP_INFLIGHT="1"))
     assert outt3.returncode == 0, outt3.stderr[-2000:]
     rt3 = json.loads(outt3.stdout.strip().splitlines()[-1])
-    assert rt3["mismatches"] == 0 and rt3["near_tie_flips"] <= 1 and rt3["failures"] == 0 and rt3["inflight"] == 3
+    assert rt3["mismatches"] == 0 and rt3["near_tie_flips"] <= 1 and rt3["failures"] == 0 and rt3["inflight"] == 1

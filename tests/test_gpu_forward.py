@@ -204,6 +204,8 @@ def test_full_size_batch_matches_oracle(pkg, weights_mod):
     other_form = any(os.environ.get(k) == "0" for k in ("PFHIP_GEMM_X3", "PFHIP_GEMM_X6", "PFHIP_ATT_X3", "PFHIP_ATT_X6", "PFHIP_PLANES"))
     assert model._lib.pfhip_debug_poke(model.handle, b"plane_forwards", 0) == (0 if other_form else 1)
     assert model.debug_poke("range_fallbacks") == 0 and model.debug_poke("always_exact") == 0
+    # ~7000 token rows: the decoder's K/V projections, FFNs and output projections ran on plane images too (round 4)
+    assert model.debug_poke("dec_plane_forwards") == (0 if other_form else 1)
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=1)

@@ -507,6 +507,9 @@ void torch_style_state(const OnnxModel& m, State& state) {
       const Array* Bm = nd.inputs.size() > 3 && !nd.inputs[3].empty() && init.count(nd.inputs[3]) ? &init[nd.inputs[3]] : nullptr;
       if (Wm.dims.size() != 3 || Rm.dims.size() != 3 || Wm.dims[1] % 4) bad("LSTM " + module + ": unexpected W / R shapes");
       const size_t dirs = (size_t)Wm.dims[0], h = (size_t)Rm.dims[2], in = (size_t)Wm.dims[2];
+      if (dirs < 1 || dirs > 2 || h == 0 || (size_t)Wm.dims[1] != 4 * h || (size_t)Rm.dims[0] != dirs || (size_t)Rm.dims[1] != 4 * h ||
+          (Bm && Bm->count() != dirs * 8 * h))
+        bad("LSTM " + module + ": W / R / B shapes do not agree");
       std::vector<float> Wv(Wm.count()), Rv(Rm.count()), Bv(Bm ? Bm->count() : 0);
       Wm.copy_to(Wv.data());
       Rm.copy_to(Rv.data());

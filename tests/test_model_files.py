@@ -169,3 +169,28 @@ def test_malformed_files_are_errors_not_crashes(mods, tmp_path):
         pkg.read_model_files("asr", str(d / "model.onnx"), **args)
     with pytest.raises(pkg.PfhipError, match="kind"):
         pkg.read_model_files("tts", str(d / "model.onnx"), **args)
+
+
+def test_damaged_files_under_address_sanitizer(mods, tmp_path):
+    """The reader built for the CPU with -fsanitize=address,undefined (tools/fuzz/model_files_fuzz.cpp) loads 400 damaged copies of
+    a valid directory — truncations, flipped bytes, huge varints, shifted framing, in the ONNX file, am.mvn and config.yaml: every
+    one is either loaded or refused with a message; the sanitizers report nothing (a report ends the process with a non-zero code)."""
+    import shutil
+    import subprocess
+    pkg, conv, wt = mods
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fuzz"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        os.path.join(root, "tools", "fuzz", "model_files_fuzz.cpp"), os.path.join(root, "asr-2pass_amd", "csrc", "model_files.cpp"),
+                        "-o", str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cfg = wt.small_config(enc_layers=2, dec_layers=1, vocab=23, contextual=0, timestamp=1, d_model=32, ffn=64, dec_ffn=64, n_head=2)     # tiny: the reader needs no device
+    man, blob = wt.synth_weights(cfg, seed=29)
+    d = tmp_path / "asr"
+    RL.write_asr_dir(str(d), conv, man, blob, cfg)
+    out = subprocess.run([str(exe), "asr", str(d), "400", "7"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["iterations"] == 400 and res["loaded"] + res["refused"] == 400 and res["refused"] >= 100 and res["loaded"] >= 20, res

@@ -139,7 +139,42 @@ __device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, 
   return make_float2(mean, rstd);
 }
 
-// OUT: 1 = fp32 C, 2 = plane images of C, 3 = both.  A / W images: rows_a / rows_w rows per K-step.  inv_scale = 1 / (weight scale).
+// Epilogue of a tile that leaves as ROW-MAJOR planes (OUT & 4: the K | V columns of the QKV projection, read by attention_p3.hip): thread =
+// (row, 8 columns), 16 lanes x 16 B = the tile's 256 bytes of a row per plane.  Cs = the accumulator tile in LDS.
+template <bool LN, int ROWS, int THREADS>
+__device__ __forceinline__ void row_planes_tile(const float* Cs, const float2* s_mr, int m0, int n0, int M, int N, float inv_scale,
+                                                const float* __restrict__ bias, const float* __restrict__ ln_colsum, unsigned char* __restrict__ Ph,
+                                                unsigned char* __restrict__ Pl, int ldp, int split_col, int tid, bool do_store) {
+  const int c8 = tid & 15, rsub = tid >> 4;
+  const int gcol = n0 + 8 * c8;
+  float bb[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bb[e] = bias ? bias[gcol + e] : 0.f; ss[e] = LN ? ln_colsum[gcol + e] : 0.f; }
+  constexpr int RPP = THREADS / 16;
+#pragma unroll
+  for (int pass = 0; pass < ROWS / RPP; ++pass) {
+    const int row = pass * RPP + rsub, grow = m0 + row;
+    const float4 a = *reinterpret_cast<const float4*>(Cs + row * kPCs + 8 * c8);
+    const float4 b = *reinterpret_cast<const float4*>(Cs + row * kPCs + 8 * c8 + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float2 mr = LN ? s_mr[row] : make_float2(0.f, 1.f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] * inv_scale;
+      if (LN) x = mr.y * (x - mr.x * ss[e]);
+      v[e] = x + bb[e];
+    }
+    uint4 hh, ll;
+    split8(v, hh, ll);
+    if (do_store && grow < M) {
+      const size_t off = ((size_t)grow * ldp + (gcol - split_col)) * 2;
+      *reinterpret_cast<uint4*>(Ph + off) = hh;
+      *reinterpret_cast<uint4*>(Pl + off) = ll;
+    }
+  }
+}
+
+// OUT: 1 = fp32 C, 2 = plane images of C, 3 = both, 5 = fp32 C for columns < split_col and row-major planes for the rest.  A / W images: rows_a / rows_w rows per K-step.  inv_scale = 1 / (weight scale).
 // FOUR waves (2 x 2, each 64 x 64 = four MFMA tiles, twelve MFMAs and eight fragment reads per K-step: 0.67 KB of LDS reads per
 // MFMA; the first form of this kernel — eight waves of 64 x 32, 1 KB per MFMA — ran 8-20 % over gemm_x3.hip and was bound by the
 // LDS reads), two workgroups per CU.
@@ -150,7 +185,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
     const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
     int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
     const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
-    float inv_scale, int* range_flag) {
+    float inv_scale, int* range_flag, int split_col) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -291,7 +326,9 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   if (LN && tid < kPM) s_mr[tid] = ln_mr;
   __syncthreads();
 
-  if (OUT & 1) {      // fp32 rows: 32 lanes x 16 B per row; the final values go back into the LDS tile when planes follow
+  if ((OUT & 4) && n0 >= split_col) {      // a K | V tile of the QKV projection: row-major planes, 16 lanes x 16 B per row and plane
+    row_planes_tile<LN, kPM, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, do_store);
+  } else if (OUT & 1) {      // fp32 rows: 32 lanes x 16 B per row; the final values go back into the LDS tile when planes follow
     const int c4 = tid & 31, rsub = tid >> 5;
     const int gcol = n0 + 4 * c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
@@ -392,7 +429,7 @@ __global__ __launch_bounds__(kQThreads, 2) void gemm_p3_256_kernel(
     const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
     int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
     const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
-    float inv_scale, int* range_flag) {
+    float inv_scale, int* range_flag, int split_col) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -599,7 +636,7 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
     const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
     int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
     const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
-    float inv_scale, int* range_flag) {
+    float inv_scale, int* range_flag, int split_col) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   int tm, tn;
@@ -700,7 +737,9 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   if (LN && tid < kHM) s_mr[tid] = ln_mr;
   __syncthreads();
 
-  if (OUT & 1) {
+  if ((OUT & 4) && n0 >= split_col) {
+    row_planes_tile<LN, kHM, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, true);
+  } else if (OUT & 1) {
     const int c4 = tid & 31, rsub = tid >> 5;
     const int gcol = n0 + 4 * c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
@@ -801,7 +840,8 @@ void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K
 #endif
 void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                     void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
-                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s, int tile_rows) {
+                    const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s, int tile_rows,
+                    int row_planes_from) {
   if (M <= 0 || N <= 0) return;
   const int tiles_n = (N + kPN - 1) / kPN;
   // 64-row tiles (three workgroups per CU) when 128-row tiles would leave most of a round of 512 slots empty
@@ -816,8 +856,8 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
   // against 47.5 / 47.1: what the loop gains from 0.75 x the bytes the single workgroup loses in its epilogue, which no second
   // workgroup covers.  Taken where the loop is long (K >= 1024); PFHIP_P3_TILE256=2 takes it wherever it fills the chip.
   static const bool q_all = [] { const char* e = getenv("PFHIP_P3_TILE256"); return e && e[0] == '2'; }();
-  const bool quad = tile_rows == kQM || (tile_rows == 0 && q_env && !half && rows_a >= kQM && (K >= 1024 || q_all) &&
-                                         100 * nq >= 85 * 256 * ((nq + 255) / 256));
+  const bool quad = row_planes_from <= 0 && (tile_rows == kQM || (tile_rows == 0 && q_env && !half && rows_a >= kQM && (K >= 1024 || q_all) &&
+                                         100 * nq >= 85 * 256 * ((nq + 255) / 256)));
   const int tmr = quad ? kQM : (half ? kHM : kPM);
   const int n_tiles = ((M + tmr - 1) / tmr) * tiles_n;
   static const int gw_env = [] { const char* e = getenv("PFHIP_P3_GW"); return e && *e ? atoi(e) : 0; }();      // experiments
@@ -833,13 +873,27 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
   {                                                                                                                             \
     if (quad)                                                                                                                   \
       launch_with_lds<gemm_p3_256_kernel<LNF, OUTM>, kQThreads>(n_tiles, kQLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
-                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
+                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
     else if (half)                                                                                                              \
       launch_with_lds<gemm_p3_64_kernel<LNF, OUTM>>(n_tiles, kHLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
-                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
+                                                    M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
     else                                                                                                                        \
       launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds + PFHIP_P3_LDS_PAD, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
-                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag); \
+                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
+  }
+  if (row_planes_from > 0) {      // the QKV projection: fp32 Q | row-major K, V planes (C and Ph both given)
+#define PFHIP_P3S(LNF)                                                                                                          \
+  {                                                                                                                             \
+    if (half)                                                                                                                   \
+      launch_with_lds<gemm_p3_64_kernel<LNF, 5>>(n_tiles, kHLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+                                                 M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
+    else                                                                                                                        \
+      launch_with_lds<gemm_p3_128_kernel<LNF, 5>>(n_tiles, kPLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+                                                  M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
+  }
+    if (ln_stats) PFHIP_P3S(true) else PFHIP_P3S(false)
+#undef PFHIP_P3S
+    return;
   }
   if (ln_stats) {
     if (out == 1) PFHIP_P3(true, 1) else if (out == 2) PFHIP_P3(true, 2) else PFHIP_P3(true, 3)

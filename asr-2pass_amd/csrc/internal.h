@@ -152,6 +152,8 @@ struct pfhip_model {
   std::vector<int> last_n;
   int plane_forwards = 0;                                       // forwards of this context that took the plane path (debug read-out)
   Buf ctxP, xP, hP;                                             // activation plane images of a large batch: context, residual stream, FFN hidden
+  Buf kvP;                                                      // K | V of an encoder layer as row-major fp16 planes (attention_p3.hip)
+  int kvplane_forwards = 0;                                     // forwards whose encoder attention took K | V as planes (debug read-out)
   Buf encP, xdP;                                                // decoder on plane operands: images of the encoder output and of the token-side residual stream
   // fp16 plane images of the decoder's large weights per layer (dec3 = the last entry: FFN only): [layer] { ffn1' | ffn2' | kv | out }
   unsigned char* d_dwplanes = nullptr;

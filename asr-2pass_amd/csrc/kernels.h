@@ -93,7 +93,19 @@ void launch_split_planes(const float* X, int ld, int rows_valid, int rows, int K
 void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
                     void* Ph, void* Pl, int rows_p, const float* bias, const float* R1, int ldr1, int M, int N, int K, bool relu,
                     const float* ln_stats, int ln_tiles, const float* ln_colsum, float* stats_out, int gw, hipStream_t s,
-                    int tile_rows = 0);      // 0: 64-row tiles when 128-row tiles would fill less than a round; 64 / 128 force one
+                    int tile_rows = 0,       // 0: 64-row tiles when 128-row tiles would fill less than a round; 64 / 128 force one
+                    int row_planes_from = 0);
+// row_planes_from = c > 0 (the encoder's QKV projection, C given): columns < c leave as fp32 rows of C, columns >= c as ROW-MAJOR fp16
+// planes Ph / Pl [M][rows_p] (rows_p = elements per plane row; column n at element n - c) — the K | V operand of attention_p3.hip.
+// c % 128 == 0; 128- and 64-row tiles only.
+// Row-major planes of an fp32 matrix (tests, tools): hi / lo [rows][ldp] fp16, cols % 8 == 0.
+void launch_split_rows(const float* X, int ld, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t s);
+// attention_x3.hip's fused attention on K / V given as row-major planes (row stride ldkv elements, K at column 0, V at column v_col of
+// each plane; head h in columns 128 h ..): tiles staged by LDS-DMA, V read through gfx950's transposing LDS read.  d_k = 128.
+void launch_attention_p3(const float* Q, int ldq, const void* kv_hi, const void* kv_lo, int ldkv, int v_col, float* O, int ldo, const int* q_off,
+                         const int* q_len, const int* kv_off, const int* kv_len, int B, int H, int max_q_len, float scale, hipStream_t s,
+                         const float* fsmn_w = nullptr, float* mem = nullptr, int ldmem = 0, bool mem_accumulate = false,
+                         void* planes_hi = nullptr, void* planes_lo = nullptr, int plane_rows = 0);
 // The product-path form of the two options above: the BF16-split kernels with the tile / column-group choice of launch_gemm_f32.
 // gemm_x6_ln_ok(M): whether launch_gemm_f32 would put the N = 512 launches of M rows on these kernels (both sides of a
 // statistics hand-off must).

@@ -135,6 +135,36 @@ int pfhip_op_attention_planes(const float* Q, int ldq, const float* K, int ldk, 
                              nullptr, 0, false, planes_hi, planes_lo, plane_rows);
   return done();
 }
+int pfhip_op_split_rows(const float* X, int ld, int rows, int cols, void* hi, void* lo, int ldp, void* stream) {
+  if (!X || !hi || !lo || rows <= 0 || cols <= 0 || cols % 8 || ld < cols || ldp < cols || ldp % 8) return (int)hipErrorInvalidValue;
+  pfhip::launch_split_rows(X, ld, rows, cols, hi, lo, ldp, S(stream));
+  return (int)hipGetLastError();
+}
+int pfhip_op_gemm_p3_qkv(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
+                         void* kv_hi, void* kv_lo, int ldkv, int q_cols, const float* bias, int M, int N, int K, const float* ln_stats,
+                         int ln_tiles, const float* ln_colsum, int tile_rows, void* stream) {
+  const int mp = (M + 127) / 128 * 128;
+  if (M <= 0 || N <= 0 || K < 16 || K % 16 || N % 128 || rows_a % 128 || rows_w % 128 || rows_a < mp || rows_w < N || !Ah || !Al || !Wh ||
+      !Wl || !C || !kv_hi || !kv_lo || q_cols <= 0 || q_cols % 128 || q_cols >= N || ldc < q_cols || ldkv < N - q_cols || ldkv % 8 ||
+      !(w_scale > 0.f) || (ln_stats && (!ln_colsum || ln_tiles <= 0)) || (tile_rows != 0 && tile_rows != 64 && tile_rows != 128))
+    return (int)hipErrorInvalidValue;
+  pfhip::launch_gemm_p3(Ah, Al, rows_a, Wh, Wl, rows_w, w_scale, C, ldc, kv_hi, kv_lo, ldkv, bias, nullptr, 0, M, N, K, false, ln_stats, ln_tiles,
+                        ln_colsum, nullptr, 4, S(stream), tile_rows, q_cols);
+  return (int)hipGetLastError();
+}
+int pfhip_op_attention_kvplanes(const float* Q, int ldq, const void* kv_hi, const void* kv_lo, int ldkv, int v_col, int total_kv_rows, float* O,
+                                int ldo, void* planes_hi, void* planes_lo, int plane_rows, const int* q_off, const int* q_len,
+                                const int* kv_off, const int* kv_len, int B, int H, int max_q_len, int total_q_rows, float scale,
+                                const float* fsmn_w, float* mem, int ldmem, int mem_accumulate, void* stream) {
+  // shapes the kernel's DMA and stores assume: 16-byte chunks of whole heads inside a plane row, both operands inside one row
+  if (!Q || !kv_hi || !kv_lo || B <= 0 || H <= 0 || ldkv % 8 || v_col % 8 || v_col < H * 128 || ldkv < v_col + H * 128 || total_kv_rows <= 0 ||
+      (!O && !planes_hi) || (planes_hi && (!planes_lo || plane_rows % 128 || total_q_rows > plane_rows)) || (O && ldo < H * 128) ||
+      (fsmn_w && (!mem || ldmem < H * 128)))
+    return (int)hipErrorInvalidValue;
+  pfhip::launch_attention_p3(Q, ldq, kv_hi, kv_lo, ldkv, v_col, O, ldo, q_off, q_len, kv_off, kv_len, B, H, max_q_len, scale, S(stream), fsmn_w,
+                             mem, ldmem, mem_accumulate != 0, planes_hi, planes_lo, plane_rows);
+  return done();
+}
 int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
                  float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream) {
   if (D > 1024) return (int)hipErrorInvalidValue;

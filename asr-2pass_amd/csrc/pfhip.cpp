@@ -725,6 +725,18 @@ pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sam
     xP = {static_cast<unsigned char*>(m->xP.p), static_cast<unsigned char*>(m->xP.p) + pd};
     hP = {static_cast<unsigned char*>(m->hP.p), static_cast<unsigned char*>(m->hP.p) + pf};
   }
+  // Third step (round 4): layers 1.. hand K and V to the attention as row-major fp16 planes written by the QKV projection's epilogue
+  // (the bytes of the fp32 columns they replace) and staged by LDS-DMA (attention_p3.hip); Q stays fp32 in qkv.  PFHIP_KV_PLANES=0
+  // keeps the fp32 hand-off and attention_x3.hip's in-loop split.
+  static const bool kv_planes_on = [] { const char* e = getenv("PFHIP_KV_PLANES"); return !(e && e[0] == '0'); }();
+  const bool kv_planes = planes && kv_planes_on && c.n_head * pfhip::kHeadDim == d;
+  Img kvP{nullptr, nullptr};
+  if (kv_planes) {
+    ++m->kvplane_forwards;
+    const size_t pk = (size_t)Mp * 2 * d * 2;
+    HIP_TRY(m->kvP.ensure(2 * pk));
+    kvP = {static_cast<unsigned char*>(m->kvP.p), static_cast<unsigned char*>(m->kvP.p) + pk};
+  }
   struct WImg { const unsigned char* hi; const unsigned char* lo; float scale; };
   auto wimg = [&](int layer, int which) -> WImg {          // 0 qkv', 1 out, 2 ffn1', 3 ffn2
     const unsigned char* base = m->d_wplanes + m->wp_layer_bytes * (size_t)layer;
@@ -749,7 +761,14 @@ pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sam
     const bool first = i == 0;
     const float* xin = first ? m->x0.f() : x;
     const int ldin = first ? FP : d, Din = first ? FD : d, Kp = first ? FP : d;
-    if (planes && !first) {
+    if (kv_planes && !first) {
+      // LayerNorm(x) Wqkv'^T on the plane images of x: Q as fp32 rows of qkv, K | V as row-major planes
+      Scope sc(m, s, K_GEMM, 2.0 * M * (double)(3 * d) * d, 4.0 * ((double)M * d + 3.0 * d * d + (double)M * 3 * d));
+      const WImg W = wimg(i, 0);
+      pfhip::launch_gemm_p3(xP.hi, xP.lo, Mp, W.hi, W.lo, 3 * d, W.scale, m->qkv.f(), 3 * d, kvP.hi, kvP.lo, 2 * d,
+                            m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, 0, M, 3 * d, d, false, m->lnstats.f(), 4, m->d_lns_qkv + (size_t)i * 3 * d,
+                            nullptr, 4, s, 0, d);
+    } else if (planes && !first) {
       // LayerNorm(x) Wqkv'^T on the plane images of x that the previous layer's FFN2 left
       gemm_pl(xP, wimg(i, 0), 3 * d, d, m->qkv.f(), 3 * d, nullptr, m->d_lnb_qkv + (size_t)i * 3 * d, nullptr, false,
               m->d_lns_qkv + (size_t)i * 3 * d, false);
@@ -766,6 +785,10 @@ pfhip_status enqueue_body(pfhip_model* m, const float* d_pcm, const int64_t* sam
       Scope sc(m, s, K_ATTN, 4.0 * attn_pairs * d + 2.0 * 11 * M * d, 24.0 * M * d);
       // fused launch: the FSMN memory goes straight into the residual stream (x += memory; x = memory in the first layer, which
       // has no residual), so the bandwidth-bound output projection reads ONE residual
+      if (kv_planes && !first)
+        pfhip::launch_attention_p3(m->qkv.f(), 3 * d, kvP.hi, kvP.lo, 2 * d, d, nullptr, 0, m->m_row_off, m->m_len, m->m_row_off, m->m_len, B,
+                                   c.n_head, m->maxT, att_scale, s, m->W(p + "fsmn.w").d, x, d, true, ctxP.hi, ctxP.lo, Mp);
+      else
       pfhip::launch_attention_fsmn(m->qkv.f(), 3 * d, m->qkv.f() + d, 3 * d, m->qkv.f() + 2 * d, 3 * d, m->ctx.f(), d, m->m_row_off,
                                    m->m_len, B, c.n_head, m->maxT, att_scale, m->W(p + "fsmn.w").d, mem_in_x ? x : m->mem.f(), d, s,
                                    mem_in_x && !first, planes ? ctxP.hi : nullptr, planes ? ctxP.lo : nullptr, Mp);
@@ -1425,7 +1448,7 @@ void pfhip_destroy(pfhip_model* m) {
   for (Buf* b : {&m->pcm, &m->meta, &m->feats, &m->x0, &m->x, &m->y, &m->qkv, &m->mem, &m->ctx, &m->hbuf, &m->enc,
                  &m->alphas, &m->counts, &m->emb, &m->xd, &m->yd, &m->hd, &m->hd2, &m->td, &m->t2, &m->qd, &m->ctxd,
                  &m->logits, &m->logp, &m->ids, &m->dmeta, &m->cat, &m->hw, &m->hwkv, &m->ts_up, &m->ts_gx, &m->ts_y, &m->ts_hx, &m->ts_a2,
-                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst, &m->ctxP, &m->xP, &m->hP, &m->encP, &m->xdP})
+                 &m->ts_alphas, &m->ts_peaks, &m->ts_meta, &m->sseg, &m->fbk, &m->d_ops, &m->kvall, &m->lnstats, &m->lnstats2, &m->kvside, &m->ts_cst, &m->ctxP, &m->xP, &m->hP, &m->encP, &m->xdP, &m->kvP})
     b->release();
   if (!m->weights_of) {          // a context borrows these
 #define X(f) if (m->f) (void)hipFree((void*)m->f);
@@ -1911,6 +1934,7 @@ pfhip_status pfhip_debug_poke(pfhip_model* m, const char* what, int value) {
     return (pfhip_status)n;
   }
   if (std::string(what) == "plane_forwards") return (pfhip_status)m->plane_forwards;        // read-out: forwards on plane-image operands
+  if (std::string(what) == "kvplane_forwards") return (pfhip_status)m->kvplane_forwards;     // ... whose attention took K | V as planes
   if (std::string(what) == "dec_plane_forwards") return (pfhip_status)m->dec_plane_forwards; // ... whose decoder took the plane path too
   if (std::string(what) == "static_bound") return (pfhip_status)std::min(m->static_bound, 2.0e9);      // read-out: the load-time activation bound
   if (std::string(what) == "always_exact") return (pfhip_status)(m->always_exact ? 1 : 0);

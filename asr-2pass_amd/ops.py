@@ -260,3 +260,58 @@ def gemm_p3(A_img, W_img, M, N, K, w_scale=1.0, bias=None, R1=None, relu=False, 
                              _p(P[1]) if P else None, Mp, _p(bias), _p(R1), R1.stride(0) if R1 is not None else 0, M, N, K,
                              1 if relu else 0, _p(ln_stats), ln_tiles, _p(ln_colsum), _p(stats_out), tile_rows, _stream()), "gemm_p3")
     return C, P
+
+
+# ---- K | V as row-major planes (csrc/attention_p3.hip) ------------------------------------------------------------------------------
+def split_rows(X, ldp=None, out=None, col=0):
+    """fp32 [R, C] (device) -> row-major planes (hi, lo): float16 tensors [R, ldp], X in columns col .. col + C - 1."""
+    lib = _lib()
+    R, C = X.shape
+    ldp = C if ldp is None else ldp
+    if out is None:
+        out = (torch.zeros((R, ldp), dtype=torch.float16, device=X.device), torch.zeros((R, ldp), dtype=torch.float16, device=X.device))
+    hi, lo = out
+    lib.pfhip_op_split_rows.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp]
+    _ck(lib.pfhip_op_split_rows(_p(X), X.stride(0), R, C, hi.data_ptr() + 2 * col, lo.data_ptr() + 2 * col, ldp, _stream()), "split_rows")
+    return hi, lo
+
+
+def gemm_p3_qkv(A_img, W_img, M, N, K, q_cols, w_scale=1.0, bias=None, ln_stats=None, ln_tiles=0, ln_colsum=None, tile_rows=0):
+    """The QKV projection on plane-image operands: returns (C [Mp, q_cols] fp32, (kv_hi, kv_lo) float16 [Mp, N - q_cols])."""
+    lib = _lib()
+    ah, al, ra = A_img
+    wh, wl, rw = W_img
+    Mp = round_up(M, 128)
+    C = torch.zeros((Mp, q_cols), dtype=torch.float32, device=ah.device)
+    kvh = torch.zeros((Mp, N - q_cols), dtype=torch.float16, device=ah.device)
+    kvl = torch.zeros((Mp, N - q_cols), dtype=torch.float16, device=ah.device)
+    lib.pfhip_op_gemm_p3_qkv.argtypes = [_vp, _vp, _ci, _vp, _vp, _ci, ctypes.c_float, _vp, _ci, _vp, _vp, _ci, _ci, _vp, _ci, _ci, _ci, _vp, _ci,
+                                         _vp, _ci, _vp]
+    _ck(lib.pfhip_op_gemm_p3_qkv(_p(ah), _p(al), ra, _p(wh), _p(wl), rw, float(w_scale), _p(C), q_cols, _p(kvh), _p(kvl), N - q_cols, q_cols,
+                                 _p(bias), M, N, K, _p(ln_stats), ln_tiles, _p(ln_colsum), tile_rows, _stream()), "gemm_p3_qkv")
+    return C, (kvh, kvl)
+
+
+def attention_kvplanes(Q, kv, v_col, q_off, q_len, kv_off, kv_len, n_head, scale, fsmn_w=None, mem=None, mem_accumulate=False,
+                       want_planes=False):
+    """attention (d_k = 128) on K | V given as row-major planes kv = (hi, lo) float16 [R, ld] (K at column 0, V at column v_col).
+    Returns the context as fp32 rows, or as (hi, lo, rows) plane images with want_planes."""
+    lib = _lib()
+    kvh, kvl = kv
+    O, P = None, None
+    rows = round_up(Q.shape[0], 128)
+    if want_planes:
+        lib.pfhip_op_plane_image_bytes.restype = ctypes.c_size_t
+        lib.pfhip_op_plane_image_bytes.argtypes = [_ci, _ci]
+        nb = int(lib.pfhip_op_plane_image_bytes(rows, n_head * 128))
+        P = (torch.zeros(nb, dtype=torch.uint8, device=Q.device), torch.zeros(nb, dtype=torch.uint8, device=Q.device), rows)
+    else:
+        O = torch.zeros((Q.shape[0], n_head * 128), dtype=torch.float32, device=Q.device)
+    lib.pfhip_op_attention_kvplanes.argtypes = [_vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci,
+                                                ctypes.c_float, _vp, _vp, _ci, _ci, _vp]
+    _ck(lib.pfhip_op_attention_kvplanes(_p(Q), Q.stride(0), _p(kvh), _p(kvl), kvh.stride(0), v_col, kvh.shape[0], _p(O),
+                                        O.stride(0) if O is not None else 0, _p(P[0]) if P else None, _p(P[1]) if P else None, rows,
+                                        _p(q_off), _p(q_len), _p(kv_off), _p(kv_len), q_off.numel(), n_head, int(q_len.max().item()),
+                                        Q.shape[0], float(scale), _p(fsmn_w), _p(mem), mem.stride(0) if mem is not None else 0,
+                                        1 if mem_accumulate else 0, _stream()), "attention_kvplanes")
+    return P if want_planes else O

@@ -58,6 +58,22 @@ int pfhip_op_attention_hd(const float* Q, int ldq, const float* K, int ldk, cons
 int pfhip_op_attention_planes(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* planes_hi, void* planes_lo,
                               int plane_rows, const int* q_off, const int* q_len, const int* kv_off, const int* kv_len, int B, int H,
                               int max_q_len, int total_q_rows, float scale, void* stream);
+/* Row-major fp16 planes of an fp32 matrix: hi = fp16_rtz(x), lo = fp16_rn(x - hi), [rows][ldp] each (cols % 8 == 0). */
+int pfhip_op_split_rows(const float* X, int ld, int rows, int cols, void* hi, void* lo, int ldp, void* stream);
+/* The encoder's QKV projection on plane-image operands (pfhip_op_gemm_p3) whose result leaves in two forms: columns < q_cols as fp32
+ * rows of C, columns >= q_cols (K | V) as row-major planes kv_hi / kv_lo [M][ldkv] (column n at element n - q_cols) — what
+ * pfhip_op_attention_kvplanes stages by LDS-DMA.  q_cols % 128 == 0; tile_rows 0 / 64 / 128. */
+int pfhip_op_gemm_p3_qkv(const void* Ah, const void* Al, int rows_a, const void* Wh, const void* Wl, int rows_w, float w_scale, float* C, int ldc,
+                         void* kv_hi, void* kv_lo, int ldkv, int q_cols, const float* bias, int M, int N, int K, const float* ln_stats,
+                         int ln_tiles, const float* ln_colsum, int tile_rows, void* stream);
+/* MatMul-Softmax-MatMul (d_k = 128) with K and V given as row-major fp16 planes (attention_p3.hip: row stride ldkv elements, K at
+ * column 0 and V at column v_col of each plane, head h in columns 128 h ..; total_kv_rows rows).  Context as fp32 rows (O) or as the
+ * plane images of pfhip_op_attention_planes (planes_hi / planes_lo / plane_rows).  fsmn_w != NULL (self-attention): also the SAN-M
+ * memory block of V into mem (+= when mem_accumulate).  Same arithmetic as pfhip_op_attention on the values hi + lo. */
+int pfhip_op_attention_kvplanes(const float* Q, int ldq, const void* kv_hi, const void* kv_lo, int ldkv, int v_col, int total_kv_rows, float* O,
+                                int ldo, void* planes_hi, void* planes_lo, int plane_rows, const int* q_off, const int* q_len,
+                                const int* kv_off, const int* kv_len, int B, int H, int max_q_len, int total_q_rows, float scale,
+                                const float* fsmn_w, float* mem, int ldmem, int mem_accumulate, void* stream);
 /* CIF integrate-and-fire (onnxruntime/src/paraformer-online.cpp:301-327) + tail slot. */
 int pfhip_op_cif(const float* hidden, int ldh, const float* alphas, const int* row_off, const int* len, int B, int D,
                  float threshold, float tail, float* stage, int* n_fires, int* token_num, void* stream);

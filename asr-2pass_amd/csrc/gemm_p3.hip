@@ -138,6 +138,22 @@ __device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, 
   if (range_flag && !(rstd > kLnRstdMin && rstd < kLnRstdMax)) atomicOr(range_flag, 2);
   return make_float2(mean, rstd);
 }
+// The same for four tiles (d_model = 512: every launch of the model) from the row's 32 bytes fetched as two 16-byte loads — requested at
+// kernel entry and first used behind the prologue's DMA issue.  The loop above fetches one value per trip with a wait in each: eight
+// dependent round trips, 4,000 cycles in front of the first DMA of a 56,000-cycle workgroup (in-kernel stamps, tools/p3_stamps.py).
+// Same operations in the same order: bit-identical.
+__device__ __forceinline__ float2 ln_row_stats4(const float4& a, const float4& b, float eps, int* range_flag) {
+  float msum = 0.f, m2 = 0.f;
+  msum += a.x; msum += a.z; msum += b.x; msum += b.z;
+  const float mean = msum / 4.0f;
+  { const float dm = a.x - mean; m2 += a.y + (float)kPN * dm * dm; }
+  { const float dm = a.z - mean; m2 += a.w + (float)kPN * dm * dm; }
+  { const float dm = b.x - mean; m2 += b.y + (float)kPN * dm * dm; }
+  { const float dm = b.z - mean; m2 += b.w + (float)kPN * dm * dm; }
+  const float rstd = 1.0f / sqrtf(m2 / (float)(4 * kPN) + eps);
+  if (range_flag && !(rstd > kLnRstdMin && rstd < kLnRstdMax)) atomicOr(range_flag, 2);
+  return make_float2(mean, rstd);
+}
 
 // Epilogue of a tile that leaves as ROW-MAJOR planes (OUT & 4: the K | V columns of the QKV projection, read by attention_p3.hip): thread =
 // (row, 8 columns), 16 lanes x 16 B = the tile's 256 bytes of a row per plane.  Cs = the accumulator tile in LDS.
@@ -194,6 +210,17 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
+#ifdef PFHIP_P3_STAMPS      // dev build (tools/p3_stamps.py): s_memtime at the boundaries inside tile (0, 0) and one mid-grid tile, into their C rows
+  const bool stamp_wg = C != nullptr && tn == 0 && (tm == 0 || tm == (M / kPM) / 2);
+  // 64 stamps per C row (the tile's own 128 columns), rows m0 + 32 wave ..
+  auto dbg_at = [&](int i) { return reinterpret_cast<unsigned long long*>(C + (size_t)(m0 + 32 * wave + (i >> 6)) * ldc) + (i & 63); };
+  const bool stamping = stamp_wg && lane == 0;
+  int n_stamp = 0;
+#define PFHIP_STAMP { asm volatile("s_nop 0" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (stamping) *dbg_at(n_stamp) = t_; ++n_stamp; }
+  PFHIP_STAMP
+#else
+#define PFHIP_STAMP
+#endif
 
   // DMA map: per K-step the block copies 16 chunks of 1 KB (4 regions x 4 chunks of 32 rows); wave w moves rows 32 w .. 32 w + 31
   // of all four regions (A hi, A lo, W hi, W lo)
@@ -223,7 +250,11 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   const int w_fr = 2 * kPPlane + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (LN && tid < kPM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
+  float4 ls0 = make_float4(0.f, 0.f, 0.f, 0.f), ls1 = ls0;      // the row's statistics of four tiles, requested now, used behind the prologue's DMAs
+  if (LN && tid < kPM && ln_tiles == 4) {
+    const float4* sp = reinterpret_cast<const float4*>(ln_stats + (size_t)min(m0 + tid, M - 1) * 8);
+    ls0 = sp[0]; ls1 = sp[1];
+  }
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -235,33 +266,56 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
 #define PFHIP_RB(G, st, p, i) if (PFHIP_P3_ABLATE < 3) G[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kPStage + (p) * kPPlane + w_fr + (i) * 32 * kPRowB));
   // step: fragments FA / FB hold K-step k; read K-step k + 1 from stage `rst` into GA / GB; DMA K-step `kdma` into stage `wst`.
   // Per accumulator: a_hi w_lo, a_lo w_hi, a_hi w_hi (the order of gemm_x3.hip).
+#ifndef PFHIP_P3_SPREAD
+#define PFHIP_P3_SPREAD 1      // the four DMA pieces of a K-step between its MFMAs (0: all four at the top of the step)
+#endif
+#define PFHIP_D1(i, wst, kdma)                                                                                        \
+  if (PFHIP_P3_SPREAD && PFHIP_P3_ABLATE != 2 && PFHIP_P3_ABLATE != 4) {                                              \
+    if (i == 0) { PFHIP_DMA1(gah + (size_t)PFHIP_KA(kdma) * ka, wst, 0) }                                             \
+    if (i == 1 && PFHIP_P3_ABLATE != 8) { PFHIP_DMA1(gal + (size_t)PFHIP_KA(kdma) * ka, wst, 1) }                     \
+    if (i == 2) { PFHIP_DMA1(gwh + (size_t)PFHIP_KW(kdma) * kw, wst, 2) }                                             \
+    if (i == 3 && PFHIP_P3_ABLATE != 8) { PFHIP_DMA1(gwl + (size_t)PFHIP_KW(kdma) * kw, wst, 3) }                     \
+    PFHIP_SB;                                                                                                         \
+  }
 #define PFHIP_STEP(FA, FB, GA, GB, wst, rst, kdma)                                                                    \
   {                                                                                                                   \
-    if (PFHIP_P3_ABLATE != 2 && PFHIP_P3_ABLATE != 4) { PFHIP_DMA(wst, kdma) } PFHIP_SB;                              \
+    PFHIP_STAMP                                                                                                       \
+    if (!PFHIP_P3_SPREAD && PFHIP_P3_ABLATE != 2 && PFHIP_P3_ABLATE != 4) { PFHIP_DMA(wst, kdma) } PFHIP_SB;          \
+    PFHIP_STAMP                                                                                                       \
     PFHIP_M(acc00, FA[0][0], FB[1][0]) PFHIP_RA(GA, rst, 0, 0) PFHIP_SB;                                              \
+    PFHIP_D1(0, wst, kdma)                                                                                            \
     PFHIP_M(acc01, FA[0][0], FB[1][1]) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                              \
     PFHIP_M(acc10, FA[0][1], FB[1][0]) PFHIP_RA(GA, rst, 0, 1) PFHIP_SB;                                              \
     PFHIP_M(acc11, FA[0][1], FB[1][1]) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                                              \
+    PFHIP_D1(1, wst, kdma)                                                                                            \
     PFHIP_M(acc00, FA[1][0], FB[0][0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_SB;                                              \
     PFHIP_M(acc01, FA[1][0], FB[0][1]) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                                              \
     PFHIP_M(acc10, FA[1][1], FB[0][0]) PFHIP_RA(GA, rst, 1, 1) PFHIP_SB;                                              \
+    PFHIP_D1(2, wst, kdma)                                                                                            \
     PFHIP_M(acc11, FA[1][1], FB[0][1]) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                                              \
     PFHIP_M(acc00, FA[0][0], FB[0][0])                                                                                \
     PFHIP_M(acc01, FA[0][0], FB[0][1])                                                                                \
+    PFHIP_D1(3, wst, kdma)                                                                                            \
     PFHIP_M(acc10, FA[0][1], FB[0][0])                                                                                \
     PFHIP_M(acc11, FA[0][1], FB[0][1])                                                                                \
+    PFHIP_STAMP                                                                                                       \
     if (PFHIP_P3_ABLATE == 1 || PFHIP_P3_ABLATE == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     \
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+    PFHIP_STAMP                                                                                                       \
     PFHIP_SB;                                                                                                         \
   }
 
   const int nk = K / kPK;
   auto kclamp = [&](int t) { return t < nk ? t : nk - 1; };
+  PFHIP_STAMP
   PFHIP_DMA(0, 0)
   PFHIP_DMA(1, kclamp(1))
   PFHIP_DMA(2, kclamp(2))
   PFHIP_DMA(3, kclamp(3))
+  PFHIP_STAMP
+  if (LN && tid < kPM) ln_mr = ln_tiles == 4 ? ln_row_stats4(ls0, ls1, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
   asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
+  PFHIP_STAMP
   PFHIP_RA(fa, 0, 0, 0) PFHIP_RA(fa, 0, 0, 1) PFHIP_RA(fa, 0, 1, 0) PFHIP_RA(fa, 0, 1, 1)
   PFHIP_RB(fb, 0, 0, 0) PFHIP_RB(fb, 0, 0, 1) PFHIP_RB(fb, 0, 1, 0) PFHIP_RB(fb, 0, 1, 1)
   if (PFHIP_P3_ABLATE >= 3) {          // timing-only builds: defined register contents
@@ -275,6 +329,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
       }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // stage 0 is free for the DMA of K-step 4
+  PFHIP_STAMP      // (stamp 4: the loop starts; four stamps per K-step follow)
   // step k: fragments f / g by parity; DMA K-step k + 4 into stage k % 4 (whose fragments this step holds in registers); read stage
   // (k + 1) % 4.  A DMA has TWO full steps to land (memory latency under load is longer than one step: the three-stage form of this
   // loop waited on vmcnt every step).
@@ -292,14 +347,17 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
 #undef PFHIP_S2
 #undef PFHIP_S3
 #undef PFHIP_STEP
+#undef PFHIP_D1
 #undef PFHIP_M
 #undef PFHIP_RA
 #undef PFHIP_RB
 #undef PFHIP_DMA
 #undef PFHIP_DMA1
 #undef PFHIP_SB
+  PFHIP_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last (redundant) DMAs must not land in the C tile
   __syncthreads();
+  PFHIP_STAMP
 #ifndef PFHIP_P3_EPI
 #define PFHIP_P3_EPI 0      // timing-only builds: 1 epilogue without its global stores, 2 no epilogue at all
 #endif
@@ -307,7 +365,9 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
     if (M < 0) C[tid] = acc00[0] + acc01[1] + acc10[2] + acc11[3];
     return;
   }
+#ifndef PFHIP_P3_STAMPS
   const bool do_store = PFHIP_P3_EPI != 1 || M < 0;
+#endif
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------------------
   float* const Cs = reinterpret_cast<float*>(lds);
@@ -325,6 +385,13 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   float2* const s_mr = reinterpret_cast<float2*>(lds + kPM * kPCs * 4);
   if (LN && tid < kPM) s_mr[tid] = ln_mr;
   __syncthreads();
+  PFHIP_STAMP
+#ifdef PFHIP_P3_STAMPS
+  const bool do_store = !stamp_wg;      // its C rows hold the stamps
+#define PFHIP_P3_STAMP_END if (stamping) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); *dbg_at(n_stamp) = __builtin_amdgcn_s_memtime(); *dbg_at(n_stamp + 1) = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define PFHIP_P3_STAMP_END
+#endif
 
   if ((OUT & 4) && n0 >= split_col) {      // a K | V tile of the QKV projection: row-major planes, 16 lanes x 16 B per row and plane
     row_planes_tile<LN, kPM, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, do_store);
@@ -403,7 +470,10 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
       }
     }
   }
+  PFHIP_P3_STAMP_END
 }
+#undef PFHIP_P3_STAMP_END
+#undef PFHIP_STAMP
 
 // ---- the 256 x 128 tile (round 4): one workgroup of EIGHT waves per CU ---------------------------------------------------------------
 // Timing-only builds of the 128 x 128 kernel above (tools/p3_probe.py, 16000 rows, us per launch QKV / out-projection / FFN1 / FFN2)
@@ -665,7 +735,11 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   const int w_fr = kHWOff + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (LN && tid < kHM) ln_mr = ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
+  float4 ls0 = make_float4(0.f, 0.f, 0.f, 0.f), ls1 = ls0;
+  if (LN && tid < kHM && ln_tiles == 4) {
+    const float4* sp = reinterpret_cast<const float4*>(ln_stats + (size_t)min(m0 + tid, M - 1) * 8);
+    ls0 = sp[0]; ls1 = sp[1];
+  }
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -695,6 +769,7 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   PFHIP_DMA(1, kclamp(1))
   PFHIP_DMA(2, kclamp(2))
   PFHIP_DMA(3, kclamp(3))
+  if (LN && tid < kHM) ln_mr = ln_tiles == 4 ? ln_row_stats4(ls0, ls1, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
   asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
   PFHIP_RA(fa, 0, 0) PFHIP_RA(fa, 0, 1)
   PFHIP_RB(fb, 0, 0, 0) PFHIP_RB(fb, 0, 0, 1) PFHIP_RB(fb, 0, 1, 0) PFHIP_RB(fb, 0, 1, 1)

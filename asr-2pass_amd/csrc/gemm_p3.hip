@@ -545,16 +545,18 @@ __global__ __launch_bounds__(kQThreads, 2) void gemm_p3_256_kernel(
   // the two newest K-steps in flight
 #define PFHIP_STEP(FA, FB, GA, GB, wst, rst, kdma)                                                                    \
   {                                                                                                                   \
-    PFHIP_QDMA(wst, kdma) PFHIP_SB;                                                                                   \
     PFHIP_M(acc00, FA[0][0], FB[1][0]) PFHIP_RA(GA, rst, 0, 0) PFHIP_SB;                                              \
+    PFHIP_QDMA1(gah + (size_t)(kdma) * ka, (wst) * kQStage + lds_a) PFHIP_SB;                                         \
     PFHIP_M(acc01, FA[0][0], FB[1][1]) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                              \
     PFHIP_M(acc10, FA[0][1], FB[1][0]) PFHIP_RA(GA, rst, 0, 1) PFHIP_SB;                                              \
     PFHIP_M(acc11, FA[0][1], FB[1][1]) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                                              \
     PFHIP_M(acc00, FA[1][0], FB[0][0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_SB;                                              \
+    PFHIP_QDMA1(gal + (size_t)(kdma) * ka, (wst) * kQStage + kQAPlane + lds_a) PFHIP_SB;                              \
     PFHIP_M(acc01, FA[1][0], FB[0][1]) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                                              \
     PFHIP_M(acc10, FA[1][1], FB[0][0]) PFHIP_RA(GA, rst, 1, 1) PFHIP_SB;                                              \
     PFHIP_M(acc11, FA[1][1], FB[0][1]) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                                              \
     PFHIP_M(acc00, FA[0][0], FB[0][0])                                                                                \
+    PFHIP_QDMA1(gww + (size_t)(kdma) * kw, (wst) * kQStage + lds_w) PFHIP_SB;                                         \
     PFHIP_M(acc01, FA[0][0], FB[0][1])                                                                                \
     PFHIP_M(acc10, FA[0][1], FB[0][0])                                                                                \
     PFHIP_M(acc11, FA[0][1], FB[0][1])                                                                                \
@@ -752,12 +754,14 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   // per accumulator: a_hi w_lo, a_lo w_hi, a_hi w_hi (the order of gemm_x3.hip and of the 128-row kernel: bit-identical results)
 #define PFHIP_STEP(FA, FB, GA, GB, wst, rst, kdma)                                                                    \
   {                                                                                                                   \
-    PFHIP_DMA(wst, kdma) PFHIP_SB;                                                                                    \
     PFHIP_M(acc0, FA[0], FB[1][0]) PFHIP_RA(GA, rst, 0) PFHIP_SB;                                                     \
+    PFHIP_DMA1(ga + (size_t)(kdma) * ka, (wst) * kHStage + lds_a) PFHIP_SB;                                           \
     PFHIP_M(acc1, FA[0], FB[1][1]) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                                  \
     PFHIP_M(acc0, FA[1], FB[0][0]) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                                                  \
+    PFHIP_DMA1(gwh + (size_t)(kdma) * kw, (wst) * kHStage + lds_w) PFHIP_SB;                                          \
     PFHIP_M(acc1, FA[1], FB[0][1]) PFHIP_RA(GA, rst, 1) PFHIP_SB;                                                     \
     PFHIP_M(acc0, FA[0], FB[0][0]) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                                                  \
+    PFHIP_DMA1(gwl + (size_t)(kdma) * kw, (wst) * kHStage + lds_w + kPPlane) PFHIP_SB;                                \
     PFHIP_M(acc1, FA[0], FB[0][1]) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                                                  \
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
     PFHIP_SB;                                                                                                         \

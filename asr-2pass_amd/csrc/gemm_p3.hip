@@ -249,6 +249,26 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   const int a_fr = ra * kPRowB + ((h ^ ((ra >> 3) & 1)) << 4);
   const int w_fr = 2 * kPPlane + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
 
+  // The epilogue's operands in the layout of its fp32 pass (thread = 4 columns x 16 rows: bias, LayerNorm column sums, the residual
+  // rows), requested NOW: fetched in the epilogue they were a chain of exposed latencies behind the loop (in-kernel stamps: 4,300
+  // cycles for the bias of a mid-grid out-projection tile, 13,000 for its residual pass); here they land under the prologue's DMAs.
+  const int e_c4 = tid & 31, e_rsub = tid >> 5, e_gcol = n0 + 4 * e_c4;
+  const bool e_cols = e_gcol + 3 < N;
+  const bool kv_tile = (OUT & 4) && n0 >= split_col;
+  float4 e_bv = make_float4(0.f, 0.f, 0.f, 0.f), e_cs = e_bv, e_r1[16];
+#pragma unroll
+  for (int pass = 0; pass < 16; ++pass) e_r1[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!kv_tile) {
+    if (bias && e_cols) e_bv = *reinterpret_cast<const float4*>(bias + e_gcol);
+    if (LN && e_cols) e_cs = *reinterpret_cast<const float4*>(ln_colsum + e_gcol);
+    if (R1 && e_cols) {
+#pragma unroll
+      for (int pass = 0; pass < 16; ++pass) {
+        const int grow = m0 + pass * 8 + e_rsub;
+        if (grow < M) e_r1[pass] = *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + e_gcol);
+      }
+    }
+  }
   float2 ln_mr = make_float2(0.f, 1.f);
   float4 ls0 = make_float4(0.f, 0.f, 0.f, 0.f), ls1 = ls0;      // the row's statistics of four tiles, requested now, used behind the prologue's DMAs
   if (LN && tid < kPM && ln_tiles == 4) {
@@ -393,41 +413,46 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
 #define PFHIP_P3_STAMP_END
 #endif
 
-  if ((OUT & 4) && n0 >= split_col) {      // a K | V tile of the QKV projection: row-major planes, 16 lanes x 16 B per row and plane
+  if (kv_tile) {      // a K | V tile of the QKV projection: row-major planes, 16 lanes x 16 B per row and plane
     row_planes_tile<LN, kPM, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, do_store);
-  } else if (OUT & 1) {      // fp32 rows: 32 lanes x 16 B per row; the final values go back into the LDS tile when planes follow
-    const int c4 = tid & 31, rsub = tid >> 5;
-    const int gcol = n0 + 4 * c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
-    if (bias && gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
-    if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
-    float4 r1v[16];                                          // the residual rows of the tile, requested in one go
+  } else {
+    // fp32 pass: 32 lanes x 16 B per row, the tile's values read from LDS in one go; the final values go to C (OUT & 1) and / or back
+    // into the LDS tile for the plane pass (OUT & 2 — planes-only output takes its arithmetic here too: same operations, same order)
+    const int c4 = e_c4, rsub = e_rsub, gcol = e_gcol;
+    float4 cv[16];
+    float2 mrv[16];
 #pragma unroll
     for (int pass = 0; pass < 16; ++pass) {
-      const int grow = m0 + pass * 8 + rsub;
-      r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int row = pass * 8 + rsub;
+      cv[pass] = *reinterpret_cast<const float4*>(Cs + row * kPCs + 4 * c4);
+      mrv[pass] = LN ? s_mr[row] : make_float2(0.f, 1.f);
     }
+#ifdef PFHIP_P3_STAMPS
+    { float keep = cv[15].x + mrv[15].x; asm volatile("" : "+v"(keep)); }
+    PFHIP_STAMP
+#endif
 #pragma unroll
     for (int pass = 0; pass < 16; ++pass) {
       const int row = pass * 8 + rsub, grow = m0 + row;
-      float4 v = *reinterpret_cast<const float4*>(Cs + row * kPCs + 4 * c4);
+      float4 v = cv[pass];
       v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
       if (LN) {
-        const float2 mr = s_mr[row];
-        v.x = mr.y * (v.x - mr.x * cs4.x); v.y = mr.y * (v.y - mr.x * cs4.y); v.z = mr.y * (v.z - mr.x * cs4.z); v.w = mr.y * (v.w - mr.x * cs4.w);
+        const float2 mr = mrv[pass];
+        v.x = mr.y * (v.x - mr.x * e_cs.x); v.y = mr.y * (v.y - mr.x * e_cs.y); v.z = mr.y * (v.z - mr.x * e_cs.z); v.w = mr.y * (v.w - mr.x * e_cs.w);
       }
-      v.x += bv.x + r1v[pass].x; v.y += bv.y + r1v[pass].y; v.z += bv.z + r1v[pass].z; v.w += bv.w + r1v[pass].w;
+      v.x += e_bv.x + e_r1[pass].x; v.y += e_bv.y + e_r1[pass].y; v.z += e_bv.z + e_r1[pass].z; v.w += e_bv.w + e_r1[pass].w;
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (do_store && grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      if ((OUT & 1) && do_store && grow < M && e_cols) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
       if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
       if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
     }
+#ifdef PFHIP_P3_STAMPS
+    PFHIP_STAMP
+#endif
     if (OUT & 2) __syncthreads();
   }
   if (OUT & 2) {      // plane images of C: thread = (row, K-step of the consumer): 64 lanes = 64 consecutive rows = 2 KB per plane, contiguous
     const int row = tid & 127, grow = m0 + row;
-    const float2 mr = (LN && OUT == 2) ? s_mr[row] : make_float2(0.f, 1.f);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = (tid >> 7) + 2 * jj;                    // 16-column group of the tile
@@ -436,23 +461,6 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
       for (int c = 0; c < 4; ++c) {
         const float4 t = *reinterpret_cast<const float4*>(Cs + row * kPCs + 16 * j + 4 * c);
         v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
-      }
-      if (OUT == 2) {     // planes only: the epilogue arithmetic happens here (the fp32 pass did not run)
-        const int gc = n0 + 16 * j;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 s4 = LN ? *reinterpret_cast<const float4*>(ln_colsum + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = v[4 * c + e] * inv_scale;
-            if (LN) x = mr.y * (x - mr.x * ss[e]);
-            x += bb[e];
-            if (relu) x = fmaxf(x, 0.f);
-            v[4 * c + e] = x;
-          }
-        }
       }
       const int ksp = (n0 >> 4) + j;                        // K-step of the consumer this column group is
 #pragma unroll

@@ -32,9 +32,9 @@ nk = K // 16
 for tm in (0, (M // 128) // 2):
     print(f"tile ({tm}, 0):")
     for w in range(4):
-        st_ = np.concatenate([Cn[128 * tm + 32 * w + j, :128].view(np.uint64) for j in range(3)])[:4 + 4 * nk + 6].astype(np.int64)
+        st_ = np.concatenate([Cn[128 * tm + 32 * w + j, :128].view(np.uint64) for j in range(3)])[:4 + 4 * nk + 8].astype(np.int64)
         pre = st_[:5]; steps = st_[4:4 + 4 * nk + 1]; post = st_[4 + 4 * nk:]
         d = np.diff(steps).reshape(nk, 4)
         print(f"  wave {w}: entry->DMA0 {pre[1]-pre[0]}, 4 stages issued {pre[2]-pre[1]}, landed+barrier {pre[3]-pre[2]}, first fragments {pre[4]-pre[3]}; "
               f"loop {steps[-1]-steps[0]} = {nk} x (stamp {d[2:,0].mean():.0f}, DMA issue {d[2:,1].mean():.0f}, MFMAs+reads {d[2:,2].mean():.0f}, wait+barrier {d[2:,3].mean():.0f}); "
-              f"drain+barrier {post[2]-post[0]}, C tile to LDS {post[3]-post[2]}, epilogue {post[4]-post[3]}; total {post[4]-pre[0]} cycles, realtime end {post[5]}")
+              f"drain+barrier {post[2]-post[0]}, C tile to LDS {post[3]-post[2]}, LDS reads {post[4]-post[3]}, fp32 pass {post[5]-post[4]}, rest {post[6]-post[5]}; total {post[6]-pre[0]} cycles")

@@ -163,3 +163,30 @@ def test_refuses_shapes_the_kernels_do_not_take(ops):
         ops.gemm_p3_qkv(a_img, w_img, 100, 384, 64, 100)                     # q_cols not a whole tile
     with pytest.raises(RuntimeError):
         ops.gemm_p3_qkv(a_img, w_img, 100, 384, 64, 384)                     # nothing left for K | V
+
+
+def test_model_forward_with_the_plane_hand_off(pkg, weights_mod, monkeypatch):
+    """PFHIP_KV_PLANES=1 (opt-in): layers 1.. of the encoder run QKV -> row-major K | V planes -> attention_p3 on a batch that takes the
+    plane path (8 x 30 s = 4000 rows).  Same token ids as the default fp32 hand-off, log-probs within 2e-5 of it (the attention is
+    bit-identical; the memory block reads V as hi + lo = 22-23 bits) and within north_star's 1e-3 of the CPU restatement."""
+    from conftest import assert_ids_match, synth_pcm
+    cfg = weights_mod.small_config(enc_layers=3, dec_layers=1, vocab=257)
+    man, blob = weights_mod.synth_weights(cfg, seed=61)
+    rng = np.random.default_rng(1)
+    utts = [synth_pcm(i, 480000 + 97 * i, rng) for i in range(8)]
+    model = pkg.ParaformerHip().InitAsr((man, blob))
+    monkeypatch.delenv("PFHIP_KV_PLANES", raising=False)
+    base = model.forward_ids(utts, want_logp=True)
+    assert model.debug_poke("plane_forwards") == 1 and model.debug_poke("kvplane_forwards") == 0
+    monkeypatch.setenv("PFHIP_KV_PLANES", "1")
+    got = model.forward_ids(utts, want_logp=True)
+    assert model.debug_poke("plane_forwards") == 2 and model.debug_poke("kvplane_forwards") == 1
+    for b in range(len(utts)):
+        assert list(got["ids"][b]) == list(base["ids"][b])
+        assert np.abs(got["logp"][b] - base["logp"][b]).max() < 2e-5
+    W = P.Weights(man, blob)
+    for b in (0, 7):
+        ref = P.forward_pcm(utts[b], W)
+        assert np.abs(got["logp"][b] - ref["logp"]).max() < 1e-3
+        assert_ids_match(got["ids"][b], ref, tie_gap=1e-3)
+    model.close()

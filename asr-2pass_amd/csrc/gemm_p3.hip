@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   float4 e_bv = make_float4(0.f, 0.f, 0.f, 0.f), e_cs = e_bv, e_r1[16];
 #pragma unroll
   for (int pass = 0; pass < 16; ++pass) e_r1[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!kv_tile) {
+  if (!kv_tile && (OUT & 1)) {
     if (bias && e_cols) e_bv = *reinterpret_cast<const float4*>(bias + e_gcol);
     if (LN && e_cols) e_cs = *reinterpret_cast<const float4*>(ln_colsum + e_gcol);
     if (R1 && e_cols) {
@@ -415,9 +415,9 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
 
   if (kv_tile) {      // a K | V tile of the QKV projection: row-major planes, 16 lanes x 16 B per row and plane
     row_planes_tile<LN, kPM, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, do_store);
-  } else {
-    // fp32 pass: 32 lanes x 16 B per row, the tile's values read from LDS in one go; the final values go to C (OUT & 1) and / or back
-    // into the LDS tile for the plane pass (OUT & 2 — planes-only output takes its arithmetic here too: same operations, same order)
+  } else if (OUT & 1) {
+    // fp32 pass: 32 lanes x 16 B per row, the tile's values read from LDS in one go; the final values go to C and, when planes follow,
+    // back into the LDS tile
     const int c4 = e_c4, rsub = e_rsub, gcol = e_gcol;
     float4 cv[16];
     float2 mrv[16];
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
       }
       v.x += e_bv.x + e_r1[pass].x; v.y += e_bv.y + e_r1[pass].y; v.z += e_bv.z + e_r1[pass].z; v.w += e_bv.w + e_r1[pass].w;
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if ((OUT & 1) && do_store && grow < M && e_cols) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      if (do_store && grow < M && e_cols) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
       if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
       if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
     }
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   }
   if (OUT & 2) {      // plane images of C: thread = (row, K-step of the consumer): 64 lanes = 64 consecutive rows = 2 KB per plane, contiguous
     const int row = tid & 127, grow = m0 + row;
+    const float2 mr = (LN && OUT == 2) ? s_mr[row] : make_float2(0.f, 1.f);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = (tid >> 7) + 2 * jj;                    // 16-column group of the tile
@@ -461,6 +462,23 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
       for (int c = 0; c < 4; ++c) {
         const float4 t = *reinterpret_cast<const float4*>(Cs + row * kPCs + 16 * j + 4 * c);
         v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+      }
+      if (OUT == 2) {     // planes only: the epilogue arithmetic happens here (the fp32 pass did not run)
+        const int gc = n0 + 16 * j;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 s4 = LN ? *reinterpret_cast<const float4*>(ln_colsum + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[4 * c + e] * inv_scale;
+            if (LN) x = mr.y * (x - mr.x * ss[e]);
+            x += bb[e];
+            if (relu) x = fmaxf(x, 0.f);
+            v[4 * c + e] = x;
+          }
+        }
       }
       const int ksp = (n0 >> 4) + j;                        // K-step of the consumer this column group is
 #pragma unroll

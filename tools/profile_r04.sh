@@ -11,3 +11,15 @@ python3 tools/pmc_by_kernel.py $O/pm > $O/pmc_mfma_busy.txt
 rm -rf $O/kt $O/pf $O/pw $O/pm
 python3 bench.py --steps 20 --warmup 5 > $O/bench_line_driver_cmd.json 2> $O/bench_driver.err
 ls -la $O; head -12 $O/pmc_mfma_busy.txt | cut -c1-200
+# in-kernel timelines (dev builds made on the build box: tools/x3_variant.sh p3st "-DPFHIP_P3_STAMPS=1" gemm_p3.hip; attpst "-DPFHIP_ATTP_STAMPS=1" attention_p3.hip)
+if [ -f build/libpfhip_p3st.so ]; then
+  PFHIP_LIB=$R/build/libpfhip_p3st.so python3 tools/p3_stamps.py qkv 2>&1 | grep -v "amdgpu.ids\|Warning\|print" > $O/p3_stamps_qkv.txt
+  PFHIP_LIB=$R/build/libpfhip_p3st.so python3 tools/p3_stamps.py out 2>&1 | grep -v "amdgpu.ids\|Warning\|print" > $O/p3_stamps_out_projection.txt
+fi
+if [ -f build/libpfhip_attpst.so ]; then
+  PFHIP_LIB=$R/build/libpfhip_attpst.so python3 tools/att_stamps.py 2>&1 | grep -v "amdgpu.ids\|Warning\|print" > $O/attention_p3_stamps.txt
+fi
+python3 tools/att_probe.py 2>&1 | grep "Lq=" > $O/attention_probe.txt
+python3 tools/p3_probe.py 2>&1 | grep -v amdgpu.ids > $O/p3_probe.txt
+if [ -f build/libpfhip_p3base.so ]; then PFHIP_LIB=$R/build/libpfhip_p3base.so python3 tools/p3_probe.py 2>&1 | grep -v amdgpu.ids >> $O/p3_probe.txt; fi
+ls -la $O

@@ -138,19 +138,30 @@ __device__ __forceinline__ float2 ln_row_stats(const float* __restrict__ stats, 
   if (range_flag && !(rstd > kLnRstdMin && rstd < kLnRstdMax)) atomicOr(range_flag, 2);
   return make_float2(mean, rstd);
 }
-// The same for four tiles (d_model = 512: every launch of the model) from the row's 32 bytes fetched as two 16-byte loads — requested at
-// kernel entry and first used behind the prologue's DMA issue.  The loop above fetches one value per trip with a wait in each: eight
-// dependent round trips, 4,000 cycles in front of the first DMA of a 56,000-cycle workgroup (in-kernel stamps, tools/p3_stamps.py).
-// Same operations in the same order: bit-identical.
-__device__ __forceinline__ float2 ln_row_stats4(const float4& a, const float4& b, float eps, int* range_flag) {
+// The same for T tiles (4: d_model = 512; 16: the decoder's LayerNorm over the 2048 hidden channels) from the row's 8 T bytes fetched as
+// T / 2 16-byte loads — requested at kernel entry and first used behind the prologue's DMA issue.  The loop above fetches one value per
+// trip with a wait in each: 2 T dependent round trips, 4,000 cycles (T = 4) in front of the first DMA of a 56,000-cycle workgroup
+// (in-kernel stamps, tools/p3_stamps.py).  Same operations in the same order: bit-identical.
+template <int T>
+struct LnRaw { float4 v[T / 2]; };
+template <int T>
+__device__ __forceinline__ void ln_raw_load(LnRaw<T>& r, const float* __restrict__ stats, int row) {
+  const float4* sp = reinterpret_cast<const float4*>(stats + (size_t)row * T * 2);
+#pragma unroll
+  for (int i = 0; i < T / 2; ++i) r.v[i] = sp[i];
+}
+template <int T>
+__device__ __forceinline__ float2 ln_row_stats_raw(const LnRaw<T>& r, float eps, int* range_flag) {
   float msum = 0.f, m2 = 0.f;
-  msum += a.x; msum += a.z; msum += b.x; msum += b.z;
-  const float mean = msum / 4.0f;
-  { const float dm = a.x - mean; m2 += a.y + (float)kPN * dm * dm; }
-  { const float dm = a.z - mean; m2 += a.w + (float)kPN * dm * dm; }
-  { const float dm = b.x - mean; m2 += b.y + (float)kPN * dm * dm; }
-  { const float dm = b.z - mean; m2 += b.w + (float)kPN * dm * dm; }
-  const float rstd = 1.0f / sqrtf(m2 / (float)(4 * kPN) + eps);
+#pragma unroll
+  for (int i = 0; i < T / 2; ++i) { msum += r.v[i].x; msum += r.v[i].z; }
+  const float mean = msum / (float)T;
+#pragma unroll
+  for (int i = 0; i < T / 2; ++i) {
+    { const float dm = r.v[i].x - mean; m2 += r.v[i].y + (float)kPN * dm * dm; }
+    { const float dm = r.v[i].z - mean; m2 += r.v[i].w + (float)kPN * dm * dm; }
+  }
+  const float rstd = 1.0f / sqrtf(m2 / (float)(T * kPN) + eps);
   if (range_flag && !(rstd > kLnRstdMin && rstd < kLnRstdMax)) atomicOr(range_flag, 2);
   return make_float2(mean, rstd);
 }
@@ -270,11 +281,10 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
     }
   }
   float2 ln_mr = make_float2(0.f, 1.f);
-  float4 ls0 = make_float4(0.f, 0.f, 0.f, 0.f), ls1 = ls0;      // the row's statistics of four tiles, requested now, used behind the prologue's DMAs
-  if (LN && tid < kPM && ln_tiles == 4) {
-    const float4* sp = reinterpret_cast<const float4*>(ln_stats + (size_t)min(m0 + tid, M - 1) * 8);
-    ls0 = sp[0]; ls1 = sp[1];
-  }
+  LnRaw<4> ls4;      // the row's statistics (four tiles, or sixteen), requested now, used behind the prologue's DMAs
+  LnRaw<16> ls16;
+  if (LN && tid < kPM && ln_tiles == 4) ln_raw_load(ls4, ln_stats, min(m0 + tid, M - 1));
+  if (LN && tid < kPM && ln_tiles == 16) ln_raw_load(ls16, ln_stats, min(m0 + tid, M - 1));
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(kPThreads, 2) void gemm_p3_128_kernel(
   PFHIP_DMA(2, kclamp(2))
   PFHIP_DMA(3, kclamp(3))
   PFHIP_STAMP
-  if (LN && tid < kPM) ln_mr = ln_tiles == 4 ? ln_row_stats4(ls0, ls1, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
+  if (LN && tid < kPM) ln_mr = ln_tiles == 4 ? ln_row_stats_raw(ls4, ln_eps, range_flag) : ln_tiles == 16 ? ln_row_stats_raw(ls16, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
   asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
   PFHIP_STAMP
   PFHIP_RA(fa, 0, 0, 0) PFHIP_RA(fa, 0, 0, 1) PFHIP_RA(fa, 0, 1, 0) PFHIP_RA(fa, 0, 1, 1)
@@ -763,11 +773,10 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   const int w_fr = kHWOff + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  float4 ls0 = make_float4(0.f, 0.f, 0.f, 0.f), ls1 = ls0;
-  if (LN && tid < kHM && ln_tiles == 4) {
-    const float4* sp = reinterpret_cast<const float4*>(ln_stats + (size_t)min(m0 + tid, M - 1) * 8);
-    ls0 = sp[0]; ls1 = sp[1];
-  }
+  LnRaw<4> ls4;
+  LnRaw<16> ls16;
+  if (LN && tid < kHM && ln_tiles == 4) ln_raw_load(ls4, ln_stats, min(m0 + tid, M - 1));
+  if (LN && tid < kHM && ln_tiles == 16) ln_raw_load(ls16, ln_stats, min(m0 + tid, M - 1));
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -799,7 +808,7 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   PFHIP_DMA(1, kclamp(1))
   PFHIP_DMA(2, kclamp(2))
   PFHIP_DMA(3, kclamp(3))
-  if (LN && tid < kHM) ln_mr = ln_tiles == 4 ? ln_row_stats4(ls0, ls1, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
+  if (LN && tid < kHM) ln_mr = ln_tiles == 4 ? ln_row_stats_raw(ls4, ln_eps, range_flag) : ln_tiles == 16 ? ln_row_stats_raw(ls16, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
   asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
   PFHIP_RA(fa, 0, 0) PFHIP_RA(fa, 0, 1)
   PFHIP_RB(fb, 0, 0, 0) PFHIP_RB(fb, 0, 0, 1) PFHIP_RB(fb, 0, 1, 0) PFHIP_RB(fb, 0, 1, 1)

@@ -729,6 +729,88 @@ __global__ __launch_bounds__(kQThreads, 2) void gemm_p3_256_kernel(
   }
 }
 
+// The epilogue of 64 tile rows that sit in the LDS image Cs (row stride kPCs) with their LayerNorm (mean, rstd) in s_mr: K | V planes,
+// fp32 rows, plane images, row statistics — the whole epilogue of the 64-row kernel, one half of the three-stage 128-row kernel's.
+template <bool LN, int OUT>
+__device__ __forceinline__ void epilogue_rows64(const int tid, float* const Cs, const float2* const s_mr, const int m0, const int n0, const int tn,
+                                                const int tiles_n, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
+                                                int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int relu,
+                                                const float* __restrict__ ln_colsum, float* __restrict__ stats_out, float inv_scale, int split_col) {
+  if ((OUT & 4) && n0 >= split_col) {
+    row_planes_tile<LN, 64, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, true);
+  } else if (OUT & 1) {
+    const int c4 = tid & 31, rsub = tid >> 5;
+    const int gcol = n0 + 4 * c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
+    if (bias && gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
+    if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
+    float4 r1v[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int grow = m0 + pass * 8 + rsub;
+      r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 8 + rsub, grow = m0 + row;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row * kPCs + 4 * c4);
+      v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
+      if (LN) {
+        const float2 mr = s_mr[row];
+        v.x = mr.y * (v.x - mr.x * cs4.x); v.y = mr.y * (v.y - mr.x * cs4.y); v.z = mr.y * (v.z - mr.x * cs4.z); v.w = mr.y * (v.w - mr.x * cs4.w);
+      }
+      v.x += bv.x + r1v[pass].x; v.y += bv.y + r1v[pass].y; v.z += bv.z + r1v[pass].z; v.w += bv.w + r1v[pass].w;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
+      if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
+      if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
+    }
+    if (OUT & 2) __syncthreads();
+  }
+  if (OUT & 2) {      // plane images of C: 64 lanes = the tile's 64 rows = 2 KB per plane, contiguous
+    const int row = tid & 63, grow = m0 + row;
+    const float2 mr = (LN && OUT == 2) ? s_mr[row] : make_float2(0.f, 1.f);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = (tid >> 6) + 4 * jj;                    // 16-column group of the tile
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(Cs + row * kPCs + 16 * j + 4 * c);
+        v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+      }
+      if (OUT == 2) {
+        const int gc = n0 + 16 * j;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 s4 = LN ? *reinterpret_cast<const float4*>(ln_colsum + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[4 * c + e] * inv_scale;
+            if (LN) x = mr.y * (x - mr.x * ss[e]);
+            x += bb[e];
+            if (relu) x = fmaxf(x, 0.f);
+            v[4 * c + e] = x;
+          }
+        }
+      }
+      const int ksp = (n0 >> 4) + j;
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const float w8[8] = {v[8 * pc], v[8 * pc + 1], v[8 * pc + 2], v[8 * pc + 3], v[8 * pc + 4], v[8 * pc + 5], v[8 * pc + 6], v[8 * pc + 7]};
+        uint4 hh, ll;
+        split8(w8, hh, ll);
+        const size_t off = image_off(ksp, grow, pc, rows_p);
+        *reinterpret_cast<uint4*>(Ph + off) = hh;
+        *reinterpret_cast<uint4*>(Pl + off) = ll;
+      }
+    }
+  }
+}
+
 // ---- the 64 x 128 tile: grids that leave most of a round of 128 x 128 tiles empty (a few utterances, the long-audio flow's packed
 // forwards, streaming rounds).  Same loop, half the rows: 4 waves as 2 x 2 (each 32 x 64 = two MFMA tiles, six MFMAs and six
 // fragment reads per K-step), a stage of 12 KB (A hi | A lo | W hi | W lo), ring of four = 48 KB: THREE workgroups per CU.
@@ -851,78 +933,152 @@ __global__ __launch_bounds__(kPThreads, 3) void gemm_p3_64_kernel(
   if (LN && tid < kHM) s_mr[tid] = ln_mr;
   __syncthreads();
 
-  if ((OUT & 4) && n0 >= split_col) {
-    row_planes_tile<LN, kHM, kPThreads>(Cs, s_mr, m0, n0, M, N, inv_scale, bias, ln_colsum, Ph, Pl, rows_p, split_col, tid, true);
-  } else if (OUT & 1) {
-    const int c4 = tid & 31, rsub = tid >> 5;
-    const int gcol = n0 + 4 * c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bv;
-    if (bias && gcol + 3 < N) bv = *reinterpret_cast<const float4*>(bias + gcol);
-    if (LN && gcol + 3 < N) cs4 = *reinterpret_cast<const float4*>(ln_colsum + gcol);
-    float4 r1v[8];
+  epilogue_rows64<LN, OUT>(tid, Cs, s_mr, m0, n0, tn, tiles_n, C, ldc, Ph, Pl, rows_p, bias, R1, ldr1, M, N, relu, ln_colsum, stats_out, inv_scale, split_col);
+}
+
+// ---- the 128 x 128 tile on a ring of THREE stages: three workgroups per CU (round 4, second half) ----------------------------------------
+// In-kernel timelines of the four-stage kernel: a workgroup spends ~30 % of its life outside its K-loop (prologue, drain, C
+// tile to LDS, epilogue arithmetic and stores) and a lone workgroup in the loop keeps the matrix pipe ~55 % busy — so with two workgroups
+// per CU the pipe idles whenever one of them is not looping.  Here the ring is 3 x 16 KB and the C tile leaves in two 64-row halves
+// through a 34-KB image (the epilogue of the 64-row kernel, twice): 48 KB of LDS, <= 168 registers, THREE workgroups per CU = three
+// waves per SIMD.  A DMA has one full K-step to land instead of two (`vmcnt(4)`); same MFMA order per accumulator as the four-stage
+// kernel: bit-identical results.
+constexpr int kP3Lds = 3 * kPStage;      // 49,152 B (a 64-row half of the C tile + 128 rows of statistics need 34,816)
+static_assert(64 * kPCs * 4 + kPM * 8 <= kP3Lds, "half of the C tile and the row statistics must fit the ring");
+template <bool LN, int OUT>
+__global__ __launch_bounds__(kPThreads, 3) void gemm_p3_128r3_kernel(
+    const unsigned char* __restrict__ Ah, const unsigned char* __restrict__ Al, int rows_a, const unsigned char* __restrict__ Wh,
+    const unsigned char* __restrict__ Wl, int rows_w, float* C, int ldc, unsigned char* __restrict__ Ph, unsigned char* __restrict__ Pl,
+    int rows_p, const float* __restrict__ bias, const float* R1, int ldr1, int M, int N, int K, int tiles_n, int n_tiles, int gw, int relu,
+    const float* __restrict__ ln_stats, int ln_tiles, float ln_eps, const float* __restrict__ ln_colsum, float* __restrict__ stats_out,
+    float inv_scale, int* range_flag, int split_col) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  int tm, tn;
+  tile_of_block_p3(blockIdx.x, n_tiles, tiles_n, gw, tm, tn);
+  const int m0 = tm * kPM, n0 = tn * kPN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // DMA map of the four-stage kernel: wave w moves rows 32 w .. 32 w + 31 of all four regions (A hi, A lo, W hi, W lo)
+  const size_t ka = (size_t)rows_a * kPRowB, kw = (size_t)rows_w * kPRowB;
+  const unsigned char* const gah = Ah + ((size_t)(m0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gal = Al + ((size_t)(m0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gwh = Wh + ((size_t)(n0 + 32 * wave)) * kPRowB + lane * 16;
+  const unsigned char* const gwl = Wl + ((size_t)(n0 + 32 * wave)) * kPRowB + lane * 16;
+  const int lds_c = wave * 1024;
+#define PFHIP_DMA1(src, stage, region)                                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                              \
+                                   (__attribute__((address_space(3))) void*)(lds + (stage) * kPStage + (region) * kPPlane + lds_c), 16, 0, 0);
+#define PFHIP_DMA(stage, ks)                                                                                          \
+  PFHIP_DMA1(gah + (size_t)(ks) * ka, stage, 0) PFHIP_DMA1(gal + (size_t)(ks) * ka, stage, 1)                         \
+  PFHIP_DMA1(gwh + (size_t)(ks) * kw, stage, 2) PFHIP_DMA1(gwl + (size_t)(ks) * kw, stage, 3)
+
+  const int ra = wr * 64 + r, rb = wc * 64 + r;
+  const int a_fr = ra * kPRowB + ((h ^ ((ra >> 3) & 1)) << 4);
+  const int w_fr = 2 * kPPlane + rb * kPRowB + ((h ^ ((rb >> 3) & 1)) << 4);
+
+  float2 ln_mr = make_float2(0.f, 1.f);
+  LnRaw<4> ls4;      // the row's statistics, requested now, used behind the prologue's DMAs
+  LnRaw<16> ls16;
+  if (LN && tid < kPM && ln_tiles == 4) ln_raw_load(ls4, ln_stats, min(m0 + tid, M - 1));
+  if (LN && tid < kPM && ln_tiles == 16) ln_raw_load(ls16, ln_stats, min(m0 + tid, M - 1));
+
+  f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int grow = m0 + pass * 8 + rsub;
-      r1v[pass] = (R1 && grow < M && gcol + 3 < N) ? *reinterpret_cast<const float4*>(R1 + (size_t)grow * ldr1 + gcol)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int row = pass * 8 + rsub, grow = m0 + row;
-      float4 v = *reinterpret_cast<const float4*>(Cs + row * kPCs + 4 * c4);
-      v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
-      if (LN) {
-        const float2 mr = s_mr[row];
-        v.x = mr.y * (v.x - mr.x * cs4.x); v.y = mr.y * (v.y - mr.x * cs4.y); v.z = mr.y * (v.z - mr.x * cs4.z); v.w = mr.y * (v.w - mr.x * cs4.w);
-      }
-      v.x += bv.x + r1v[pass].x; v.y += bv.y + r1v[pass].y; v.z += bv.z + r1v[pass].z; v.w += bv.w + r1v[pass].w;
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (grow < M && gcol + 3 < N) *reinterpret_cast<float4*>(C + (size_t)grow * ldc + gcol) = v;
-      if (OUT & 2) *reinterpret_cast<float4*>(Cs + row * kPCs + 4 * c4) = v;
-      if (stats_out) tile_row_stats(v, grow, M, tn, tiles_n, c4, stats_out);
-    }
-    if (OUT & 2) __syncthreads();
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+  half8 fa[2][2], fb[2][2], ga_[2][2], gb_[2][2];          // [plane][tile]
+#define PFHIP_SB __builtin_amdgcn_sched_barrier(0)
+#define PFHIP_M(acc, A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0); PFHIP_SB;
+#define PFHIP_RA(G, st, p, i) G[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kPStage + (p) * kPPlane + a_fr + (i) * 32 * kPRowB));
+#define PFHIP_RB(G, st, p, i) G[p][i] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4*>(lds + (st) * kPStage + (p) * kPPlane + w_fr + (i) * 32 * kPRowB));
+  // step k: fragments FA / FB hold K-step k; read K-step k + 1 from stage `rst` into GA / GB; DMA K-step `kdma` (= k + 3) into stage
+  // `wst` (= k % 3, whose fragments this step holds in registers), one piece behind every third MFMA.  Per accumulator: a_hi w_lo,
+  // a_lo w_hi, a_hi w_hi.
+#define PFHIP_STEP(FA, FB, GA, GB, wst, rst, kdma)                                                                    \
+  {                                                                                                                   \
+    PFHIP_M(acc00, FA[0][0], FB[1][0]) PFHIP_RA(GA, rst, 0, 0) PFHIP_SB;                                              \
+    PFHIP_DMA1(gah + (size_t)(kdma) * ka, wst, 0) PFHIP_SB;                                                           \
+    PFHIP_M(acc01, FA[0][0], FB[1][1]) PFHIP_RB(GB, rst, 0, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc10, FA[0][1], FB[1][0]) PFHIP_RA(GA, rst, 0, 1) PFHIP_SB;                                              \
+    PFHIP_M(acc11, FA[0][1], FB[1][1]) PFHIP_RB(GB, rst, 0, 1) PFHIP_SB;                                              \
+    PFHIP_DMA1(gal + (size_t)(kdma) * ka, wst, 1) PFHIP_SB;                                                           \
+    PFHIP_M(acc00, FA[1][0], FB[0][0]) PFHIP_RA(GA, rst, 1, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc01, FA[1][0], FB[0][1]) PFHIP_RB(GB, rst, 1, 0) PFHIP_SB;                                              \
+    PFHIP_M(acc10, FA[1][1], FB[0][0]) PFHIP_RA(GA, rst, 1, 1) PFHIP_SB;                                              \
+    PFHIP_DMA1(gwh + (size_t)(kdma) * kw, wst, 2) PFHIP_SB;                                                           \
+    PFHIP_M(acc11, FA[1][1], FB[0][1]) PFHIP_RB(GB, rst, 1, 1) PFHIP_SB;                                              \
+    PFHIP_M(acc00, FA[0][0], FB[0][0])                                                                                \
+    PFHIP_M(acc01, FA[0][0], FB[0][1])                                                                                \
+    PFHIP_DMA1(gwl + (size_t)(kdma) * kw, wst, 3) PFHIP_SB;                                                           \
+    PFHIP_M(acc10, FA[0][1], FB[0][0])                                                                                \
+    PFHIP_M(acc11, FA[0][1], FB[0][1])                                                                                \
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+    PFHIP_SB;                                                                                                         \
   }
-  if (OUT & 2) {      // plane images of C: 64 lanes = the tile's 64 rows = 2 KB per plane, contiguous
-    const int row = tid & 63, grow = m0 + row;
-    const float2 mr = (LN && OUT == 2) ? s_mr[row] : make_float2(0.f, 1.f);
+
+  const int nk = K / kPK;
+  auto kclamp = [&](int t) { return t < nk ? t : nk - 1; };
+  PFHIP_DMA(0, 0)
+  PFHIP_DMA(1, kclamp(1))
+  PFHIP_DMA(2, kclamp(2))
+  if (LN && tid < kPM) ln_mr = ln_tiles == 4 ? ln_row_stats_raw(ls4, ln_eps, range_flag) : ln_tiles == 16 ? ln_row_stats_raw(ls16, ln_eps, range_flag) : ln_row_stats(ln_stats, ln_tiles, ln_eps, min(m0 + tid, M - 1), range_flag);
+  asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");          // K-steps 0 and 1 have landed, for every wave
+  PFHIP_RA(fa, 0, 0, 0) PFHIP_RA(fa, 0, 0, 1) PFHIP_RA(fa, 0, 1, 0) PFHIP_RA(fa, 0, 1, 1)
+  PFHIP_RB(fb, 0, 0, 0) PFHIP_RB(fb, 0, 0, 1) PFHIP_RB(fb, 0, 1, 0) PFHIP_RB(fb, 0, 1, 1)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // stage 0 is free for the DMA of K-step 3
+  // fragment sets alternate and stages cycle mod 3: the pattern repeats every six steps
+#define PFHIP_T0(kt) PFHIP_STEP(fa, fb, ga_, gb_, 0, 1, kclamp((kt) + 3))
+#define PFHIP_T1(kt) PFHIP_STEP(ga_, gb_, fa, fb, 1, 2, kclamp((kt) + 4))
+#define PFHIP_T2(kt) PFHIP_STEP(fa, fb, ga_, gb_, 2, 0, kclamp((kt) + 5))
+#define PFHIP_T3(kt) PFHIP_STEP(ga_, gb_, fa, fb, 0, 1, kclamp((kt) + 6))
+#define PFHIP_T4(kt) PFHIP_STEP(fa, fb, ga_, gb_, 1, 2, kclamp((kt) + 7))
+#define PFHIP_T5(kt) PFHIP_STEP(ga_, gb_, fa, fb, 2, 0, kclamp((kt) + 8))
+  int kt = 0;
+  for (; kt + 5 < nk; kt += 6) { PFHIP_T0(kt) PFHIP_T1(kt) PFHIP_T2(kt) PFHIP_T3(kt) PFHIP_T4(kt) PFHIP_T5(kt) }
+  if (kt < nk) PFHIP_T0(kt)
+  if (kt + 1 < nk) PFHIP_T1(kt)
+  if (kt + 2 < nk) PFHIP_T2(kt)
+  if (kt + 3 < nk) PFHIP_T3(kt)
+  if (kt + 4 < nk) PFHIP_T4(kt)
+#undef PFHIP_T0
+#undef PFHIP_T1
+#undef PFHIP_T2
+#undef PFHIP_T3
+#undef PFHIP_T4
+#undef PFHIP_T5
+#undef PFHIP_STEP
+#undef PFHIP_M
+#undef PFHIP_RA
+#undef PFHIP_RB
+#undef PFHIP_DMA
+#undef PFHIP_DMA1
+#undef PFHIP_SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last (redundant) DMAs must not land in the C tile
+  __syncthreads();
+
+  // ---- epilogue: the tile leaves in two halves of 64 rows (waves 0-1, then 2-3) through the 64-row image ------------------------------
+  float* const Cs = reinterpret_cast<float*>(lds);
+  float2* const s_mr = reinterpret_cast<float2*>(lds + 64 * kPCs * 4);
+  if (LN && tid < kPM) s_mr[tid] = ln_mr;
+#pragma unroll 1
+  for (int hf = 0; hf < 2; ++hf) {
+    if (wr == hf) {
+      float* cw = Cs + (4 * h) * kPCs + wc * 64 + r;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = (tid >> 6) + 4 * jj;                    // 16-column group of the tile
-      float v[16];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 t = *reinterpret_cast<const float4*>(Cs + row * kPCs + 16 * j + 4 * c);
-        v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
-      }
-      if (OUT == 2) {
-        const int gc = n0 + 16 * j;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 s4 = LN ? *reinterpret_cast<const float4*>(ln_colsum + gc + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = v[4 * c + e] * inv_scale;
-            if (LN) x = mr.y * (x - mr.x * ss[e]);
-            x += bb[e];
-            if (relu) x = fmaxf(x, 0.f);
-            v[4 * c + e] = x;
-          }
-        }
-      }
-      const int ksp = (n0 >> 4) + j;
-#pragma unroll
-      for (int pc = 0; pc < 2; ++pc) {
-        const float w8[8] = {v[8 * pc], v[8 * pc + 1], v[8 * pc + 2], v[8 * pc + 3], v[8 * pc + 4], v[8 * pc + 5], v[8 * pc + 6], v[8 * pc + 7]};
-        uint4 hh, ll;
-        split8(w8, hh, ll);
-        const size_t off = image_off(ksp, grow, pc, rows_p);
-        *reinterpret_cast<uint4*>(Ph + off) = hh;
-        *reinterpret_cast<uint4*>(Pl + off) = ll;
+      for (int e = 0; e < 16; ++e) {
+        const int ro = ((e & 3) + 8 * (e >> 2)) * kPCs;
+        cw[ro] = acc00[e];
+        cw[ro + 32] = acc01[e];
+        cw[ro + 32 * kPCs] = acc10[e];
+        cw[ro + 32 * kPCs + 32] = acc11[e];
       }
     }
+    __syncthreads();
+    epilogue_rows64<LN, OUT>(tid, Cs, s_mr + 64 * hf, m0 + 64 * hf, n0, tn, tiles_n, C, ldc, Ph, Pl, rows_p, bias, R1, ldr1, M, N, relu, ln_colsum,
+                             stats_out, inv_scale, split_col);
+    __syncthreads();                                        // the second half overwrites the image
   }
 }
 
@@ -972,6 +1128,13 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
   static const bool q_all = [] { const char* e = getenv("PFHIP_P3_TILE256"); return e && e[0] == '2'; }();
   const bool quad = row_planes_from <= 0 && (tile_rows == kQM || (tile_rows == 0 && q_env && !half && rows_a >= kQM && (K >= 1024 || q_all) &&
                                          100 * nq >= 85 * 256 * ((nq + 255) / 256)));
+  // the three-stage 128-row kernel (three workgroups per CU) for grids of more than two rounds of its 768 slots.  Measured
+  // (tools/p3_probe.py, 16000 rows, two same-session pairs): FFN1' (2000 tiles) 119.7 / 121.5 us against 123.8 / 122.6 on the four-stage
+  // kernel, QKV' (1500 tiles) 100.2 / 99.0 against 98.3 / 96.3, out-projection (500) level — a third workgroup per CU does not lift the
+  // loop (it is the CU's operand path that is busy), it only smooths the rounds of a long grid.  PFHIP_P3_R3=0 / 1:
+  // never / wherever the 128-row tile is taken.
+  const int r3_env = [] { const char* e = getenv("PFHIP_P3_R3"); return e && *e ? atoi(e) : -1; }();      // (read per launch: tests switch it)
+  const bool ring3 = !quad && !half && (r3_env == 1 || (r3_env != 0 && ((M + kPM - 1) / kPM) * tiles_n > 1536));
   const int tmr = quad ? kQM : (half ? kHM : kPM);
   const int n_tiles = ((M + tmr - 1) / tmr) * tiles_n;
   static const int gw_env = [] { const char* e = getenv("PFHIP_P3_GW"); return e && *e ? atoi(e) : 0; }();      // experiments
@@ -991,6 +1154,9 @@ void launch_gemm_p3(const void* Ah, const void* Al, int rows_a, const void* Wh, 
     else if (half)                                                                                                              \
       launch_with_lds<gemm_p3_64_kernel<LNF, OUTM>>(n_tiles, kHLds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
+    else if (ring3)                                                                                                             \
+      launch_with_lds<gemm_p3_128r3_kernel<LNF, OUTM>>(n_tiles, kP3Lds, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
+                                                     M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \
     else                                                                                                                        \
       launch_with_lds<gemm_p3_128_kernel<LNF, OUTM>>(n_tiles, kPLds + PFHIP_P3_LDS_PAD, s, ah, al, rows_a, wh, wl, rows_w, C, ldc, ph, pl, rows_p, bias, R1, ldr1, \
                                                      M, N, K, tiles_n, n_tiles, gw, relu ? 1 : 0, ln_stats, ln_tiles, 1e-12f, ln_colsum, stats_out, inv, launch_ctx().range_flag, row_planes_from); \

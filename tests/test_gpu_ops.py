@@ -414,6 +414,42 @@ def test_gemm_on_pre_split_operands(ops, M, N, K, relu):
         assert np.abs(C3.cpu().numpy()[:M] - ref2 @ W2.astype(np.float64).T).max() < 2 * tol * max(1.0, np.sqrt(N / 512)) * max(1.0, np.abs(ref2).max() / 4)
 
 
+def test_three_stage_tile_is_bit_identical(ops, monkeypatch):
+    """gemm_p3_128r3_kernel (ring of three stages, three workgroups per CU, the C tile out in two 64-row halves; picked by itself for
+    grids beyond 1536 tiles, PFHIP_P3_R3=1 forces it): same MFMA order and epilogue arithmetic as the four-stage kernel — every output
+    form must match it bit for bit, ragged M and a K that leaves a tail of the six-step pattern included."""
+    rng = np.random.default_rng(77)
+    for M, N, K, ln in ((1000, 512, 512, False), (777, 1536, 512, True), (300, 256, 80, False), (2050, 512, 2048, False)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        R1 = rng.standard_normal(((M + 127) // 128 * 128, N)).astype(np.float32)
+        ws = ops.best_w_scale(float(np.abs(W).max()))
+        a_img, w_img = ops.split_planes(dev(A)), ops.split_planes(dev(W), scale=ws)
+        kw = {}
+        if ln:
+            Mp = (M + 127) // 128 * 128
+            stats = np.zeros((Mp, 4, 2), np.float32)
+            t = A.reshape(M, 4, 128).astype(np.float64)
+            stats[:M, :, 0] = t.mean(2)
+            stats[:M, :, 1] = ((t - t.mean(2, keepdims=True)) ** 2).sum(2)
+            kw = dict(ln_stats=dev(stats), ln_tiles=4, ln_colsum=dev(W.astype(np.float64).sum(1).astype(np.float32)))
+        outs = []
+        for r3 in ("0", "1"):
+            monkeypatch.setenv("PFHIP_P3_R3", r3)
+            st = torch.zeros(((M + 127) // 128 * 128, N // 128, 2), device="cuda")
+            C, P = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=None if ln else dev(R1), relu=ln, want_c=True,
+                               want_planes=True, stats_out=None if ln else st, tile_rows=128, **kw)
+            _, P2 = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), relu=True, want_c=False, want_planes=True, tile_rows=128, **kw)
+            outs.append((C.cpu().numpy()[:M], P[0].cpu().numpy(), P[1].cpu().numpy(), P2[0].cpu().numpy(), P2[1].cpu().numpy(), st.cpu().numpy()[:M]))
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y)
+        monkeypatch.delenv("PFHIP_P3_R3")
+        if not ln:
+            ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + R1[:M]
+            assert np.abs(outs[1][0] - ref).max() < 3e-5 * max(1.0, np.sqrt(K / 512))
+
+
 def test_gemm_on_pre_split_operands_refuses_bad_shapes(ops):
     """The operator checks on the host what its grid and DMA assume; a refused call launches nothing."""
     A = dev(np.ones((128, 64), np.float32))

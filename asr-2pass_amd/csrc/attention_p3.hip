@@ -337,6 +337,7 @@ __global__ __launch_bounds__(512, 1) void attention_p3_kernel(
   auto phase_s = [&](int kt, int lead) __attribute__((always_inline)) {
     const int cur = kt & (kRing - 1);
     const bool first_tile = kt < 0;      // (timing-only builds: never true, unknown to the compiler)
+    (void)first_tile;
     const int tk = cur * kBuf + kf0, tv = cur * kBuf + vf0;
     unsigned vad[4][2];
 #pragma unroll
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void attention_p3_kernel(
   auto phase_pv = [&](int kt, int lead) __attribute__((always_inline)) {
     const int cur = kt & (kRing - 1);
     const bool first_tile = kt < 0;
+    (void)first_tile;
     const int tv = cur * kBuf + vf0;
     unsigned vad[4][2];
 #pragma unroll

@@ -450,6 +450,43 @@ def test_three_stage_tile_is_bit_identical(ops, monkeypatch):
             assert np.abs(outs[1][0] - ref).max() < 3e-5 * max(1.0, np.sqrt(K / 512))
 
 
+def test_plane_operand_tiles_agree_on_random_shapes(ops, monkeypatch):
+    """Twelve random (M, N, K) — ragged row counts, K from one K-step to 130, every tail of the four- and six-step loop patterns — through
+    the 64-, 128- (four- and three-stage) and 256-row tiles of gemm_p3.hip: all five C / plane outputs bit-identical, and the fp32
+    result within the two-plane bound of the fp64 product."""
+    rng = np.random.default_rng(4242)
+    for case in range(12):
+        M = int(rng.integers(1, 1400))
+        N = 128 * int(rng.integers(1, 5))
+        K = 16 * int(rng.integers(1, 131))
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        Mp = (M + 127) // 128 * 128
+        R1 = rng.standard_normal((Mp, N)).astype(np.float32)
+        ws = ops.best_w_scale(float(np.abs(W).max()))
+        a_img, w_img = ops.split_planes(dev(A)), ops.split_planes(dev(W), scale=ws)
+        relu = bool(case & 1)
+        outs = []
+        for tr, r3 in ((128, "0"), (128, "1"), (64, "0"), (256, "0")):
+            if tr == 256 and Mp < 256:
+                continue
+            monkeypatch.setenv("PFHIP_P3_R3", r3)
+            st = torch.zeros((Mp, N // 128, 2), device="cuda")
+            C, P = ops.gemm_p3(a_img, w_img, M, N, K, w_scale=ws, bias=dev(bias), R1=dev(R1), relu=relu, want_c=True, want_planes=True,
+                               stats_out=st, tile_rows=tr)
+            outs.append((tr, r3, C.cpu().numpy()[:M], ops.planes_to_float(P[0], P[1], P[2], N)[:M], st.cpu().numpy()[:M]))
+        monkeypatch.delenv("PFHIP_P3_R3")
+        for tr, r3, C, Pf, st in outs[1:]:
+            assert np.array_equal(C, outs[0][2]), (case, M, N, K, tr, r3)
+            assert np.array_equal(Pf, outs[0][3]), (case, M, N, K, tr, r3)
+            assert np.array_equal(st, outs[0][4]), (case, M, N, K, tr, r3)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + R1[:M]
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert np.abs(outs[0][2] - ref).max() < 3e-5 * max(1.0, np.sqrt(K / 512)), (case, M, N, K)
+
+
 def test_gemm_on_pre_split_operands_refuses_bad_shapes(ops):
     """The operator checks on the host what its grid and DMA assume; a refused call launches nothing."""
     A = dev(np.ones((128, 64), np.float32))

@@ -189,9 +189,23 @@ __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float* __r
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float best = -INFINITY;
   int bidx = 0x7fffffff;
-  for (int c = threadIdx.x; c < V; c += 256) {
-    const float x = lr[c];
-    if (x > best) { best = x; bidx = c; }     // strict '>' keeps the first maximum within a thread
+  int bad = 0;                                  // a NaN never wins a comparison: non-finite logits are looked for element by element
+  if ((V & 3) == 0 && (ldl & 3) == 0) {         // 16-byte loads (every vocabulary of the model: 8404 = 4 x 2101 columns, padded rows)
+    for (int c4 = threadIdx.x; 4 * c4 < V; c4 += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(lr + 4 * c4);
+      const int c = 4 * c4;
+      if (x.x > best) { best = x.x; bidx = c; }     // strict '>' in column order keeps the first maximum within a thread
+      if (x.y > best) { best = x.y; bidx = c + 1; }
+      if (x.z > best) { best = x.z; bidx = c + 2; }
+      if (x.w > best) { best = x.w; bidx = c + 3; }
+      bad |= (int)!(fabsf(x.x) < INFINITY) | (int)!(fabsf(x.y) < INFINITY) | (int)!(fabsf(x.z) < INFINITY) | (int)!(fabsf(x.w) < INFINITY);
+    }
+  } else {
+    for (int c = threadIdx.x; c < V; c += 256) {
+      const float x = lr[c];
+      if (x > best) { best = x; bidx = c; }     // strict '>' keeps the first maximum within a thread
+      bad |= (int)!(fabsf(x) < INFINITY);
+    }
   }
   // wave arg-max, ties -> smaller index (util.cpp:63-74 scans left to right with strict '>')
 #pragma unroll
@@ -207,6 +221,11 @@ __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float* __r
 #pragma unroll
   for (int i = 1; i < 4; ++i)
     if (s_max[i] > m || (s_max[i] == m && s_idx[i] < mi)) { m = s_max[i]; mi = s_idx[i]; }
+  if (!logp) {      // ids only (greedy search): no second pass over the row
+    if (range_flag && __any(bad)) { if (lane == 0) atomicOr(range_flag, 1); }
+    if (threadIdx.x == 0) ids[row] = mi;
+    return;
+  }
   float sum = 0.f;
   for (int c = threadIdx.x; c < V; c += 256) sum += expf(lr[c] - m);
   sum = wave_sum(sum);

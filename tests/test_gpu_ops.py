@@ -239,6 +239,15 @@ def test_logsoftmax_argmax_first_max_wins(ops):
     z = x[:, :V] - x[:, :V].max(-1, keepdims=True)
     ref = z - np.log(np.exp(z).sum(-1, keepdims=True))
     assert np.abs(logp - ref).max() < 1e-5
+    # ids only (the greedy path of the offline forward): one pass, 16-byte loads where V % 4 == 0 — same first-maximum rule
+    for V2 in (1003, 1004, 8):
+        y = rng.standard_normal((37, Vp)).astype(np.float32)
+        y[3, 701] = y[3, 22] = 9.0
+        y[4, :V2] = -5.0
+        y[5, V2:] = 100.0
+        y[6, 3] = y[6, 2] = y[6, 1] = 7.5       # a tie inside one 16-byte load
+        _, ids2 = ops.logsoftmax_argmax(dev(y), V=V2, want_logp=False)
+        assert np.array_equal(ids2.cpu().numpy(), y[:, :V2].argmax(-1))
 
 
 def test_gemm_random_shapes_all_kernels(ops):
